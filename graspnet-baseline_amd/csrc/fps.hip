@@ -1,0 +1,249 @@
+// fps.hip -- furthest point sampling for gfx950 (wave64, one workgroup per cloud).
+//
+// Replaces pointnet2/_ext_src/src/sampling_gpu.cu:74-234 (+ sampling.cpp:70-91).
+//
+// The reference runs `bs = opt_n_threads(n)` threads; thread `tid` strides over
+// k = tid, tid+bs, ... and a shared-memory tree picks the block arg-max.  Its
+// result is:  argmax_k temp[k]  with ties resolved by the total order
+//     rank(k) = ( bitrev_log2(bs)(k % bs) ,  k / bs )            (lexicographic, smaller wins)
+// (tree keeps the lower slot on ties at every level => LSB-first order of the
+// thread id; within a thread strict '>' keeps the lowest k).  Instead of
+// re-enacting that block we lay the cloud out IN RANK ORDER:
+//     position p = bitrev(k % bs) * Q + k / bs,   Q = ceil(n / bs)
+// and give thread t the contiguous positions [t*PPT, (t+1)*PPT).  "Lowest
+// position among equal maxima" is then simply lowest (wave, lane, slot), which
+// a ballot + find-first-set delivers for free.
+//
+// Register-resident variant (n*... <= 24576 positions): every thread keeps its
+// PPT points (x,y,z) and their running min-distance in VGPRs for the whole
+// 2047-iteration chain; one iteration = PPT distance updates per lane, a DPP
+// wave arg-max, one LDS exchange + one barrier across the waves, and one
+// broadcast load of the winner's coordinates.  Nothing but idx (and optionally
+// the sampled coordinates) is written to HBM; the cloud is read once.
+//
+// Distances are evaluated exactly as sampling_gpu.cu:108-109 writes them
+// (no FMA contraction; this file is compiled with -ffp-contract=off).
+#include "gn_common.h"
+
+namespace gn {
+
+__device__ __forceinline__ int bitrev_bits(int v, int bits) {
+  return bits ? (int)(__brev((unsigned)v) >> (32 - bits)) : 0;
+}
+
+// position in rank order -> original point index, or -1 for padding
+__device__ __forceinline__ int pos_to_k(int p, int bs, int lg, int Q, int n) {
+  const int r = p / Q;
+  const int q = p - r * Q;
+  if (r >= bs) return -1;
+  const int k = q * bs + bitrev_bits(r, lg);
+  return k < n ? k : -1;
+}
+
+template <int NT, int PPT>
+__global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ xyz, int n, int m,
+                                                      int bs, int lg, int Q,
+                                                      int32_t *__restrict__ idx,
+                                                      float *__restrict__ new_xyz) {
+  constexpr int NW = NT / 64;
+  __shared__ float s_val[2][16];
+  __shared__ int s_pos[2][16];
+
+  const int b = blockIdx.x;
+  xyz += (size_t)b * n * 3;
+  idx += (size_t)b * m;
+  if (new_xyz) new_xyz += (size_t)b * m * 3;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+
+  float px[PPT], py[PPT], pz[PPT], tmp[PPT];
+#pragma unroll
+  for (int s = 0; s < PPT; ++s) {
+    const int k = pos_to_k(t * PPT + s, bs, lg, Q, n);
+    float x = 0.f, y = 0.f, z = 0.f, t0 = -1.0f;
+    if (k >= 0) {
+      x = xyz[k * 3 + 0];
+      y = xyz[k * 3 + 1];
+      z = xyz[k * 3 + 2];
+      const float mag = (x * x) + (y * y) + (z * z);
+      // sampling_gpu.cu:105-106: `if (mag <= 1e-3) continue;` (float vs double literal).
+      // A skipped point never updates temp and is never a candidate: temp = -1 does both.
+      t0 = ((double)mag <= 1e-3) ? -1.0f : 1e10f;   // 1e10 = sampling.cpp:78-80
+    }
+    px[s] = x; py[s] = y; pz[s] = z; tmp[s] = t0;
+  }
+
+  float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
+  if (t == 0) {
+    idx[0] = 0;
+    if (new_xyz) { new_xyz[0] = x1; new_xyz[1] = y1; new_xyz[2] = z1; }
+  }
+
+  for (int j = 1; j < m; ++j) {
+    float best = -1.0f;
+    int bslot = 0;
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+      const float dx = px[s] - x1, dy = py[s] - y1, dz = pz[s] - z1;
+      const float d = dx * dx + dy * dy + dz * dz;
+      const float d2 = __builtin_fminf(d, tmp[s]);
+      tmp[s] = d2;
+      const bool gt = d2 > best;
+      best = gt ? d2 : best;
+      bslot = gt ? s : bslot;
+    }
+    // ---- wave arg-max, lowest lane among equal maxima
+    const float wmax = wave_max(best);
+    const unsigned long long eq = __ballot(best == wmax);
+    const int src = eq ? (__ffsll((long long)eq) - 1) : 0;
+    const int wpos = __builtin_amdgcn_readlane(t * PPT + bslot, src);
+    const int buf = j & 1;
+    if (lane == 0) {
+      s_val[buf][wave] = wmax;
+      s_pos[buf][wave] = wpos;
+    }
+    __syncthreads();
+    // ---- across waves (every wave redoes the tiny reduction; lowest wave wins ties)
+    const float v = lane < NW ? s_val[buf][lane] : -2.0f;
+    const int pp = lane < NW ? s_pos[buf][lane] : 0;
+    const float gmax = __builtin_bit_cast(
+        float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row16_max(v))));
+    const unsigned long long eq2 = __ballot(v == gmax) & 0xFFFFull;
+    const int w = eq2 ? (__ffsll((long long)eq2) - 1) : 0;
+    const int gpos = __builtin_amdgcn_readlane(pp, w);
+    // all candidates skipped -> best=-1,besti=0 in every reference thread -> index 0
+    int k = gmax >= 0.0f ? pos_to_k(gpos, bs, lg, Q, n) : 0;
+    k = __builtin_amdgcn_readfirstlane(k < 0 ? 0 : k);
+    x1 = xyz[k * 3 + 0];
+    y1 = xyz[k * 3 + 1];
+    z1 = xyz[k * 3 + 2];
+    if (t == 0) {
+      idx[j] = k;
+      if (new_xyz) { new_xyz[j * 3 + 0] = x1; new_xyz[j * 3 + 1] = y1; new_xyz[j * 3 + 2] = z1; }
+    }
+  }
+}
+
+// Any-n fallback: running min-distances live in the HBM workspace (the
+// reference's `temp`), the cloud is re-read (L2-resident) every iteration.
+// Ties are resolved with the same rank order, compared explicitly.
+__global__ __launch_bounds__(1024) void fps_global_kernel(const float *__restrict__ xyz, int n, int m,
+                                                           int bs, int lg, int Q,
+                                                           float *__restrict__ temp,
+                                                           int32_t *__restrict__ idx,
+                                                           float *__restrict__ new_xyz) {
+  constexpr int NT = 1024, NW = NT / 64;
+  __shared__ float s_val[2][16];
+  __shared__ int s_rank[2][16];
+  const int b = blockIdx.x;
+  xyz += (size_t)b * n * 3;
+  temp += (size_t)b * n;
+  idx += (size_t)b * m;
+  if (new_xyz) new_xyz += (size_t)b * m * 3;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int bmask = bs - 1;
+
+  for (int k = t; k < n; k += NT) {
+    const float x = xyz[k * 3 + 0], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
+    const float mag = (x * x) + (y * y) + (z * z);
+    temp[k] = ((double)mag <= 1e-3) ? -1.0f : 1e10f;
+  }
+  float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
+  if (t == 0) {
+    idx[0] = 0;
+    if (new_xyz) { new_xyz[0] = x1; new_xyz[1] = y1; new_xyz[2] = z1; }
+  }
+  // each thread only ever touches its own temp[k] entries: no barrier needed for temp
+  for (int j = 1; j < m; ++j) {
+    float best = -1.0f;
+    int brank = 0x7fffffff;
+    for (int k = t; k < n; k += NT) {
+      const float dx = xyz[k * 3 + 0] - x1, dy = xyz[k * 3 + 1] - y1, dz = xyz[k * 3 + 2] - z1;
+      const float d = dx * dx + dy * dy + dz * dz;
+      const float d2 = __builtin_fminf(d, temp[k]);
+      temp[k] = d2;
+      const int rank = bitrev_bits(k & bmask, lg) * Q + (k >> lg);
+      const bool take = (d2 > best) || (d2 == best && rank < brank);
+      best = take ? d2 : best;
+      brank = take ? rank : brank;
+    }
+    const float wmax = wave_max(best);
+    const int wrank = wave_min_i(best == wmax ? brank : 0x7fffffff);
+    const int buf = j & 1;
+    if (lane == 0) { s_val[buf][wave] = wmax; s_rank[buf][wave] = wrank; }
+    __syncthreads();
+    const float v = lane < NW ? s_val[buf][lane] : -2.0f;
+    const int rr = lane < NW ? s_rank[buf][lane] : 0x7fffffff;
+    const float gmax = __builtin_bit_cast(
+        float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row16_max(v))));
+    const int grank = __builtin_amdgcn_readfirstlane(row16_min_i(v == gmax ? rr : 0x7fffffff));
+    int k = 0;
+    if (gmax >= 0.0f && grank != 0x7fffffff) {
+      const int r = grank / Q, q = grank - r * Q;
+      k = q * bs + bitrev_bits(r, lg);
+    }
+    x1 = xyz[k * 3 + 0];
+    y1 = xyz[k * 3 + 1];
+    z1 = xyz[k * 3 + 2];
+    if (t == 0) {
+      idx[j] = k;
+      if (new_xyz) { new_xyz[j * 3 + 0] = x1; new_xyz[j * 3 + 1] = y1; new_xyz[j * 3 + 2] = z1; }
+    }
+  }
+}
+
+// pointnet2/_ext_src/include/cuda_utils.h:18-24 opt_n_threads()
+static int ref_block_size(int n) {
+  int p = 0;
+  while ((2 << p) <= n) ++p;  // floor(log2 n)
+  int t = 1 << p;
+  return t > 512 ? 512 : (t < 1 ? 1 : t);
+}
+
+static const int kRegCapacity = 24576;  // largest NT*PPT instantiated below
+
+}  // namespace gn
+
+extern "C" size_t gn_fps_workspace_bytes(int b, int n) {
+  if (b <= 0 || n <= 0) return 0;
+  const int bs = gn::ref_block_size(n);
+  const int Q = (n + bs - 1) / bs;
+  if ((long)bs * Q <= gn::kRegCapacity) return 0;
+  return (size_t)b * (size_t)n * sizeof(float);
+}
+
+extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m, void *workspace,
+                                          int32_t *idx, float *new_xyz, gn_stream_t stream) {
+  using namespace gn;
+  GN_REQUIRE(b >= 0 && n >= 1 && m >= 0, "furthest_point_sampling: bad sizes b=%d n=%d m=%d", b, n, m);
+  if (b == 0 || m == 0) return GN_OK;
+  GN_REQUIRE(xyz && idx, "furthest_point_sampling: null pointer");
+  GN_REQUIRE((long)n * 3 < 0x7fffffffL, "furthest_point_sampling: n too large");
+  const int bs = ref_block_size(n);
+  int lg = 0;
+  while ((1 << lg) < bs) ++lg;
+  const int Q = (n + bs - 1) / bs;
+  const long need = (long)bs * Q;
+  hipStream_t s = as_stream(stream);
+#define GN_FPS_LAUNCH(NT, PPT)                                                                    \
+  hipLaunchKernelGGL((fps_reg_kernel<NT, PPT>), dim3(b), dim3(NT), 0, s, xyz, n, m, bs, lg, Q, idx, \
+                     new_xyz)
+  if (need <= 256 * 2) GN_FPS_LAUNCH(256, 2);
+  else if (need <= 256 * 4) GN_FPS_LAUNCH(256, 4);
+  else if (need <= 1024 * 2) GN_FPS_LAUNCH(1024, 2);
+  else if (need <= 1024 * 4) GN_FPS_LAUNCH(1024, 4);
+  else if (need <= 1024 * 8) GN_FPS_LAUNCH(1024, 8);
+  else if (need <= 1024 * 12) GN_FPS_LAUNCH(1024, 12);
+  else if (need <= 1024 * 16) GN_FPS_LAUNCH(1024, 16);
+  else if (need <= 1024 * 20) GN_FPS_LAUNCH(1024, 20);
+  else if (need <= 1024 * 24) GN_FPS_LAUNCH(1024, 24);
+  else {
+    GN_REQUIRE(workspace != nullptr, "furthest_point_sampling: workspace required for n=%d", n);
+    hipLaunchKernelGGL(fps_global_kernel, dim3(b), dim3(1024), 0, s, xyz, n, m, bs, lg, Q,
+                       (float *)workspace, idx, new_xyz);
+  }
+#undef GN_FPS_LAUNCH
+  GN_CHECK_LAUNCH("furthest_point_sampling");
+  return GN_OK;
+}

@@ -1,0 +1,102 @@
+// query.hip -- ball query and cylinder query for gfx950.
+//
+// Replaces pointnet2/_ext_src/src/ball_query_gpu.cu:14-59 and
+// cylinder_query_gpu.cu:9-68.  The reference gives each centre to ONE thread
+// that scans the cloud serially; here ONE WAVE owns a centre: the 64 lanes test
+// 64 consecutive points at once, a 64-bit ballot + prefix popcount assigns the
+// output slots in index order (so "first nsample hits in index order" is kept
+// exactly), and the wave leaves the scan as soon as it has nsample hits.
+// The predicate is evaluated exactly as the reference writes it (this file is
+// built with -ffp-contract=off).
+#include "gn_common.h"
+
+namespace gn {
+
+constexpr int QUERY_WAVES = 4;  // waves (= centres in flight) per workgroup
+
+template <bool CYL>
+__global__ __launch_bounds__(QUERY_WAVES * 64) void query_kernel(
+    const float *__restrict__ new_xyz, const float *__restrict__ xyz, const float *__restrict__ rot,
+    int n, int m, float radius, float hmin, float hmax, int nsample, int32_t *__restrict__ idx) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * QUERY_WAVES + (threadIdx.x >> 6);
+  if (j >= m) return;  // wave-uniform
+  xyz += (size_t)b * n * 3;
+  const float *c = new_xyz + ((size_t)b * m + j) * 3;
+  int32_t *row = idx + ((size_t)b * m + j) * nsample;
+
+  const float radius2 = radius * radius;  // ball_query_gpu.cu:27
+  const float cx = c[0], cy = c[1], cz = c[2];
+  float r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0, r8 = 0;
+  if (CYL) {
+    const float *r = rot + ((size_t)b * m + j) * 9;
+    r0 = r[0]; r1 = r[1]; r2 = r[2]; r3 = r[3]; r4 = r[4]; r5 = r[5]; r6 = r[6]; r7 = r[7]; r8 = r[8];
+  }
+
+  int cnt = 0;
+  int first = 0;
+  for (int k0 = 0; k0 < n && cnt < nsample; k0 += 64) {
+    const int k = k0 + lane;
+    bool hit = false;
+    if (k < n) {
+      const float px = xyz[k * 3 + 0], py = xyz[k * 3 + 1], pz = xyz[k * 3 + 2];
+      if (CYL) {
+        // cylinder_query_gpu.cu:36-46
+        const float x = px - cx, y = py - cy, z = pz - cz;
+        const float x_rot = r0 * x + r3 * y + r6 * z;
+        const float y_rot = r1 * x + r4 * y + r7 * z;
+        const float z_rot = r2 * x + r5 * y + r8 * z;
+        const float d2 = y_rot * y_rot + z_rot * z_rot;
+        hit = d2 < radius2 && x_rot > hmin && x_rot < hmax;
+      } else {
+        // ball_query_gpu.cu:33-38
+        const float d2 = (cx - px) * (cx - px) + (cy - py) * (cy - py) + (cz - pz) * (cz - pz);
+        hit = d2 < radius2;
+      }
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (mask) {
+      if (cnt == 0) first = k0 + __ffsll((long long)mask) - 1;
+      const int slot = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+      if (hit && slot < nsample) row[slot] = k;
+      cnt += __popcll(mask);
+    }
+  }
+  // unfilled slots repeat the first hit (ball_query_gpu.cu:39-43); no hit -> zeros
+  // (the reference's torch::zeros output, ball_query.cpp:24-26)
+  if (cnt < nsample)
+    for (int l = cnt + lane; l < nsample; l += 64) row[l] = first;
+}
+
+template <bool CYL>
+static int launch_query(const float *new_xyz, const float *xyz, const float *rot, int b, int n, int m,
+                        float radius, float hmin, float hmax, int nsample, int32_t *idx,
+                        gn_stream_t stream, const char *name) {
+  GN_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0, "%s: bad sizes", name);
+  if (b == 0 || m == 0 || nsample == 0) return GN_OK;
+  GN_REQUIRE(new_xyz && xyz && idx && (!CYL || rot), "%s: null pointer", name);
+  GN_REQUIRE(b <= 65535, "%s: batch > 65535 unsupported", name);
+  GN_REQUIRE((long)n * 3 < 0x7fffffffL, "%s: n too large", name);
+  dim3 grid((m + QUERY_WAVES - 1) / QUERY_WAVES, b);
+  hipLaunchKernelGGL((query_kernel<CYL>), grid, dim3(QUERY_WAVES * 64), 0, as_stream(stream), new_xyz,
+                     xyz, rot, n, m, radius, hmin, hmax, nsample, idx);
+  GN_CHECK_LAUNCH(name);
+  return GN_OK;
+}
+
+}  // namespace gn
+
+extern "C" int gn_ball_query(const float *new_xyz, const float *xyz, int b, int n, int m, float radius,
+                             int nsample, int32_t *idx, gn_stream_t stream) {
+  return gn::launch_query<false>(new_xyz, xyz, nullptr, b, n, m, radius, 0.f, 0.f, nsample, idx, stream,
+                                 "ball_query");
+}
+
+extern "C" int gn_cylinder_query(const float *new_xyz, const float *xyz, const float *rot, int b, int n,
+                                 int m, float radius, float hmin, float hmax, int nsample, int32_t *idx,
+                                 gn_stream_t stream) {
+  return gn::launch_query<true>(new_xyz, xyz, rot, b, n, m, radius, hmin, hmax, nsample, idx, stream,
+                                "cylinder_query");
+}

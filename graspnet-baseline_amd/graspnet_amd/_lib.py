@@ -1,0 +1,77 @@
+"""ctypes loader for libgraspnet_hip.so (the C-ABI of include/graspnet_hip.h).
+
+There is NO fallback: if the HIP library has not been built, or a call
+returns an error, this raises.  The product path never routes through the CPU
+oracle or through torch re-implementations of the operators.
+"""
+import ctypes
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)                      # graspnet-baseline_amd/
+LIB_PATH = os.path.join(_ROOT, "lib", "libgraspnet_hip.so")
+CSRC = os.path.join(_ROOT, "csrc")
+
+_lib = None
+
+_c_int, _c_float, _c_void_p, _c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/graspnet_hip.h declares
+SIGNATURES = {
+    "gn_last_error": (ctypes.c_char_p, []),
+    "gn_version": (ctypes.c_char_p, []),
+    "gn_fps_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
+    "gn_furthest_point_sampling": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "gn_gather_points": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "gn_gather_points_grad": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "gn_ball_query": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_int, _c_void_p, _c_void_p]),
+    "gn_cylinder_query": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_int, _c_void_p, _c_void_p]),
+    "gn_group_points": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "gn_group_points_grad": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "gn_three_nn": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "gn_three_interpolate": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "gn_three_interpolate_grad": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "gn_knn": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+}
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into lib/libgraspnet_hip.so (hipcc, in-tree)."""
+    cmd = ["make", "-C", CSRC, "-j8", "all"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libgraspnet_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C graspnet-baseline_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().gn_last_error().decode("utf-8", "replace")
+        raise RuntimeError("%s failed (gn_status %d): %s" % (what, status, msg))
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(t):
+    """The current torch stream of t's device, as the void* the C ABI takes."""
+    import torch
+    return torch.cuda.current_stream(t.device).cuda_stream

@@ -1,0 +1,178 @@
+"""Drop-in for the reference's native module `pointnet2._ext`
+(pointnet2/_ext_src/src/bindings.cpp:12-27): same function names, positional
+signatures, return types and error behaviour, implemented by hand-written
+gfx950 kernels behind the C ABI in include/graspnet_hip.h.
+
+Error behaviour mirrored from pointnet2/_ext_src/include/utils.h:10-30 and the
+wrappers in pointnet2/_ext_src/src/*.cpp: a failed check raises RuntimeError
+("<arg> must be a contiguous tensor" / "... a float tensor" / "... an int
+tensor" / "... a CUDA tensor"); CPU tensors raise "CPU not supported" exactly
+like the reference (there is no CPU path upstream either).
+Outputs are freshly allocated on the input's device; kernels are enqueued on
+the current torch stream; nothing synchronises.
+"""
+import torch
+
+from . import _lib as L
+
+
+def _contig(t, name):
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be a contiguous tensor" % name)
+
+
+def _float(t, name):
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s must be a float tensor" % name)
+
+
+def _int(t, name):
+    if t.dtype != torch.int32:
+        raise RuntimeError("%s must be an int tensor" % name)
+
+
+def _cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA tensor" % name)
+
+
+def _dispatch(first, others):
+    """First tensor decides the device (e.g. ball_query.cpp:20-34)."""
+    if not first.is_cuda:
+        raise RuntimeError("CPU not supported")
+    for t, name in others:
+        _cuda(t, name)
+    return L.lib(), L.stream_of(first)
+
+
+def furthest_point_sampling(points, nsamples):
+    """(B,N,3) f32 -> (B,nsamples) i32   [sampling.cpp:70-91]"""
+    _contig(points, "points"); _float(points, "points")
+    lib, st = _dispatch(points, [])
+    b, n = points.size(0), points.size(1)
+    out = torch.empty((b, nsamples), dtype=torch.int32, device=points.device)
+    wsb = lib.gn_fps_workspace_bytes(b, n)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=points.device) if wsb else None
+    with torch.cuda.device(points.device):
+        L.check(lib.gn_furthest_point_sampling(points.data_ptr(), b, n, int(nsamples), L.ptr(ws),
+                                               out.data_ptr(), None, st), "furthest_point_sampling")
+    return out
+
+
+def gather_points(points, idx):
+    """(B,C,N) f32, (B,M) i32 -> (B,C,M)   [sampling.cpp:20-42]"""
+    _contig(points, "points"); _contig(idx, "idx"); _float(points, "points"); _int(idx, "idx")
+    lib, st = _dispatch(points, [(idx, "idx")])
+    b, c, n = points.shape
+    m = idx.size(1)
+    out = torch.empty((b, c, m), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        L.check(lib.gn_gather_points(points.data_ptr(), idx.data_ptr(), b, c, n, m, out.data_ptr(), st),
+                "gather_points")
+    return out
+
+
+def gather_points_grad(grad_out, idx, n):
+    """(B,C,M) f32, (B,M) i32, n -> (B,C,n)   [sampling.cpp:44-68]"""
+    _contig(grad_out, "grad_out"); _contig(idx, "idx"); _float(grad_out, "grad_out"); _int(idx, "idx")
+    lib, st = _dispatch(grad_out, [(idx, "idx")])
+    b, c, m = grad_out.shape
+    out = torch.empty((b, c, int(n)), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        L.check(lib.gn_gather_points_grad(grad_out.data_ptr(), idx.data_ptr(), b, c, int(n), m,
+                                          out.data_ptr(), st), "gather_points_grad")
+    return out
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    """(B,M,3), (B,N,3), r, ns -> (B,M,ns) i32   [ball_query.cpp:13-37]"""
+    _contig(new_xyz, "new_xyz"); _contig(xyz, "xyz"); _float(new_xyz, "new_xyz"); _float(xyz, "xyz")
+    lib, st = _dispatch(new_xyz, [(xyz, "xyz")])
+    b, m = new_xyz.size(0), new_xyz.size(1)
+    n = xyz.size(1)
+    out = torch.empty((b, m, int(nsample)), dtype=torch.int32, device=new_xyz.device)
+    with torch.cuda.device(new_xyz.device):
+        L.check(lib.gn_ball_query(new_xyz.data_ptr(), xyz.data_ptr(), b, n, m, float(radius), int(nsample),
+                                  out.data_ptr(), st), "ball_query")
+    return out
+
+
+def cylinder_query(new_xyz, xyz, rot, radius, hmin, hmax, nsample):
+    """(B,M,3), (B,N,3), (B,M,9), r, hmin, hmax, ns -> (B,M,ns) i32   [cylinder_query.cpp:10-37]"""
+    _contig(new_xyz, "new_xyz"); _contig(xyz, "xyz"); _contig(rot, "rot")
+    _float(new_xyz, "new_xyz"); _float(xyz, "xyz"); _float(rot, "rot")
+    lib, st = _dispatch(new_xyz, [(xyz, "xyz"), (rot, "rot")])
+    b, m = new_xyz.size(0), new_xyz.size(1)
+    n = xyz.size(1)
+    out = torch.empty((b, m, int(nsample)), dtype=torch.int32, device=new_xyz.device)
+    with torch.cuda.device(new_xyz.device):
+        L.check(lib.gn_cylinder_query(new_xyz.data_ptr(), xyz.data_ptr(), rot.data_ptr(), b, n, m,
+                                      float(radius), float(hmin), float(hmax), int(nsample),
+                                      out.data_ptr(), st), "cylinder_query")
+    return out
+
+
+def group_points(points, idx):
+    """(B,C,N) f32, (B,NP,NS) i32 -> (B,C,NP,NS)   [group_points.cpp:17-40]"""
+    _contig(points, "points"); _contig(idx, "idx"); _float(points, "points"); _int(idx, "idx")
+    lib, st = _dispatch(points, [(idx, "idx")])
+    b, c, n = points.shape
+    npoints, nsample = idx.size(1), idx.size(2)
+    out = torch.empty((b, c, npoints, nsample), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        L.check(lib.gn_group_points(points.data_ptr(), idx.data_ptr(), b, c, n, npoints, nsample,
+                                    out.data_ptr(), st), "group_points")
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    """(B,C,NP,NS) f32, (B,NP,NS) i32, n -> (B,C,n)   [group_points.cpp:42-66]"""
+    _contig(grad_out, "grad_out"); _contig(idx, "idx"); _float(grad_out, "grad_out"); _int(idx, "idx")
+    lib, st = _dispatch(grad_out, [(idx, "idx")])
+    b, c, npoints, nsample = grad_out.shape
+    out = torch.empty((b, c, int(n)), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        L.check(lib.gn_group_points_grad(grad_out.data_ptr(), idx.data_ptr(), b, c, int(n), npoints, nsample,
+                                         out.data_ptr(), st), "group_points_grad")
+    return out
+
+
+def three_nn(unknowns, knows):
+    """(B,n,3), (B,m,3) -> [dist2 (B,n,3) f32 (squared), idx (B,n,3) i32]   [interpolate.cpp:19-45]"""
+    _contig(unknowns, "unknowns"); _contig(knows, "knows"); _float(unknowns, "unknowns"); _float(knows, "knows")
+    lib, st = _dispatch(unknowns, [(knows, "knows")])
+    b, n = unknowns.size(0), unknowns.size(1)
+    m = knows.size(1)
+    dist2 = torch.empty((b, n, 3), dtype=torch.float32, device=unknowns.device)
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device=unknowns.device)
+    with torch.cuda.device(unknowns.device):
+        L.check(lib.gn_three_nn(unknowns.data_ptr(), knows.data_ptr(), b, n, m, dist2.data_ptr(),
+                                idx.data_ptr(), st), "three_nn")
+    return [dist2, idx]
+
+
+def three_interpolate(points, idx, weight):
+    """(B,C,m) f32, (B,n,3) i32, (B,n,3) f32 -> (B,C,n)   [interpolate.cpp:47-75]"""
+    _contig(points, "points"); _contig(idx, "idx"); _contig(weight, "weight")
+    _float(points, "points"); _int(idx, "idx"); _float(weight, "weight")
+    lib, st = _dispatch(points, [(idx, "idx"), (weight, "weight")])
+    b, c, m = points.shape
+    n = idx.size(1)
+    out = torch.empty((b, c, n), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        L.check(lib.gn_three_interpolate(points.data_ptr(), idx.data_ptr(), weight.data_ptr(), b, c, m, n,
+                                         out.data_ptr(), st), "three_interpolate")
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    """(B,C,n) f32, (B,n,3) i32, (B,n,3) f32, m -> (B,C,m)   [interpolate.cpp:77-104]"""
+    _contig(grad_out, "grad_out"); _contig(idx, "idx"); _contig(weight, "weight")
+    _float(grad_out, "grad_out"); _int(idx, "idx"); _float(weight, "weight")
+    lib, st = _dispatch(grad_out, [(idx, "idx"), (weight, "weight")])
+    b, c, n = grad_out.shape
+    out = torch.empty((b, c, int(m)), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        L.check(lib.gn_three_interpolate_grad(grad_out.data_ptr(), idx.data_ptr(), weight.data_ptr(), b, c, n,
+                                              int(m), out.data_ptr(), st), "three_interpolate_grad")
+    return out

@@ -1,0 +1,118 @@
+/*
+ * graspnet_hip.h -- C ABI of the MI355X (gfx950) GraspNet inference library
+ * (libgraspnet_hip.so).
+ *
+ * This is the drop-in boundary: one entry point per function of the
+ * reference's native operator modules
+ *   pointnet2._ext            (pointnet2/_ext_src/src/bindings.cpp:12-27)
+ *   knn_pytorch.knn_pytorch   (knn/src/vision.cpp:3-5)
+ * plus the fused stage entry points used behind models/graspnet.py's
+ * GraspNet.forward / pred_decode.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless said otherwise;
+ *     tensors are dense, row-major, in the reference's layouts;
+ *   - inputs are borrowed and never modified; outputs are fully written by
+ *     the callee (no pre-zeroing needed, unlike ball_query.cpp:24-26);
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); calls
+ *     only enqueue work, they never synchronise or allocate;
+ *   - return 0 on success, a negative gn_status otherwise; nothing calls
+ *     exit() (the reference's CUDA_CHECK_ERRORS does, cuda_utils.h:35-44);
+ *   - floating-point tests that decide an index (distance / radius / height
+ *     comparisons) are evaluated exactly as written in the reference kernels,
+ *     left to right, one rounding per operation, no FMA contraction.
+ */
+#ifndef GRASPNET_HIP_H
+#define GRASPNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *gn_stream_t;
+
+typedef enum gn_status {
+  GN_OK = 0,
+  GN_ERR_INVALID_ARG = -1,   /* null pointer, negative size, unsupported shape */
+  GN_ERR_LAUNCH = -2,        /* hipGetLastError() != hipSuccess after a launch  */
+  GN_ERR_NO_DEVICE = -3,
+  GN_ERR_WORKSPACE = -4      /* workspace too small                              */
+} gn_status;
+
+/* Human-readable text for the last error on this thread ("" if none). */
+const char *gn_last_error(void);
+/* Library / build identification, e.g. "graspnet_hip 0.1 gfx950". */
+const char *gn_version(void);
+
+/* ------------------------------------------------------------------ *
+ *  pointnet2._ext operators                                          *
+ * ------------------------------------------------------------------ */
+
+/* furthest_point_sampling(points (B,N,3) f32, nsamples) -> idx (B,M) i32
+ * replaces sampling.cpp:70-91 + sampling_gpu.cu:74-234.
+ * Semantics kept: idx[0]=0; points with x^2+y^2+z^2 <= 1e-3 are never
+ * selected; ties resolved in the reference's block-tree order for block size
+ * opt_n_threads(N).  `workspace` must hold gn_fps_workspace_bytes(B,N) bytes
+ * (the reference's `temp` scratch, sampling.cpp:78-80); it may be NULL when
+ * that function returns 0.  new_xyz (B,M,3) is optional (NULL to skip): the
+ * sampled coordinates, i.e. gather_points() fused in. */
+size_t gn_fps_workspace_bytes(int b, int n);
+int gn_furthest_point_sampling(const float *xyz, int b, int n, int m, void *workspace,
+                               int32_t *idx, float *new_xyz, gn_stream_t stream);
+
+/* gather_points(points (B,C,N) f32, idx (B,M) i32) -> (B,C,M)   sampling.cpp:20-42 */
+int gn_gather_points(const float *points, const int32_t *idx, int b, int c, int n, int m,
+                     float *out, gn_stream_t stream);
+/* gather_points_grad(grad_out (B,C,M), idx (B,M), n) -> (B,C,N)  sampling.cpp:44-68
+ * (float atomic scatter-add like the reference: sum order not reproducible) */
+int gn_gather_points_grad(const float *grad_out, const int32_t *idx, int b, int c, int n, int m,
+                          float *grad_points, gn_stream_t stream);
+
+/* ball_query(new_xyz (B,M,3), xyz (B,N,3), radius, nsample) -> idx (B,M,nsample) i32
+ * replaces ball_query.cpp:13-37 + ball_query_gpu.cu:14-59: first `nsample`
+ * points in index order with d2 < radius^2 (strict); unfilled slots repeat the
+ * first hit; a ball with no hit yields zeros. */
+int gn_ball_query(const float *new_xyz, const float *xyz, int b, int n, int m, float radius,
+                  int nsample, int32_t *idx, gn_stream_t stream);
+
+/* cylinder_query(new_xyz (B,M,3), xyz (B,N,3), rot (B,M,9), radius, hmin, hmax, nsample)
+ * -> idx (B,M,nsample) i32; replaces cylinder_query.cpp:10-37 + cylinder_query_gpu.cu:9-68. */
+int gn_cylinder_query(const float *new_xyz, const float *xyz, const float *rot, int b, int n, int m,
+                      float radius, float hmin, float hmax, int nsample, int32_t *idx,
+                      gn_stream_t stream);
+
+/* group_points(points (B,C,N), idx (B,NP,NS)) -> (B,C,NP,NS)   group_points.cpp:17-40 */
+int gn_group_points(const float *points, const int32_t *idx, int b, int c, int n, int npoints,
+                    int nsample, float *out, gn_stream_t stream);
+/* group_points_grad(grad_out (B,C,NP,NS), idx, n) -> (B,C,N)    group_points.cpp:42-66
+ * (float atomic scatter-add like the reference) */
+int gn_group_points_grad(const float *grad_out, const int32_t *idx, int b, int c, int n,
+                         int npoints, int nsample, float *grad_points, gn_stream_t stream);
+
+/* three_nn(unknown (B,N,3), known (B,M,3)) -> dist2 (B,N,3) f32 SQUARED, idx (B,N,3) i32
+ * replaces interpolate.cpp:19-45 + interpolate_gpu.cu:14-75. */
+int gn_three_nn(const float *unknown, const float *known, int b, int n, int m, float *dist2,
+                int32_t *idx, gn_stream_t stream);
+/* three_interpolate(points (B,C,M), idx (B,N,3), weight (B,N,3)) -> (B,C,N)  interpolate.cpp:47-75 */
+int gn_three_interpolate(const float *points, const int32_t *idx, const float *weight, int b, int c,
+                         int m, int n, float *out, gn_stream_t stream);
+/* three_interpolate_grad(grad_out (B,C,N), idx, weight, m) -> (B,C,M)        interpolate.cpp:77-104 */
+int gn_three_interpolate_grad(const float *grad_out, const int32_t *idx, const float *weight, int b,
+                              int c, int n, int m, float *grad_points, gn_stream_t stream);
+
+/* ------------------------------------------------------------------ *
+ *  knn_pytorch.knn_pytorch.knn                                       *
+ * ------------------------------------------------------------------ */
+/* knn(ref (B,D,NR) f32, query (B,D,NQ) f32, idx (B,K,NQ) i64 filled in place) ; 1-BASED indices,
+ * distance ascending, lower ref index first among equal distances (knn.h:12-65, knn.cu:36-176,
+ * knn_cpu.cpp:4-56).  scratch: B*K*NQ floats (the reference's per-call distance scratch, knn.h:33). */
+int gn_knn(const float *ref, const float *query, int b, int d, int nr, int nq, int k, int64_t *idx,
+           float *scratch, gn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRASPNET_HIP_H */

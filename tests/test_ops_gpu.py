@@ -1,0 +1,164 @@
+"""GPU parity: every operator of the C ABI (through the pointnet2._ext / knn_pytorch drop-in
+bindings) against the CPU oracle on the same seeded inputs.  Index outputs must be BIT-EXACT."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from graspnet_amd import pointnet2_ext
+    return pointnet2_ext
+
+
+def _cloud(seed, b, n, variant="uniform"):
+    from graspnet_amd import synthetic as S
+    return S.make_batch(seed, b, n, variant)
+
+
+def _dev(t):
+    return t.cuda()
+
+
+@pytest.mark.parametrize("n,m,variant", [(20000, 2048, "uniform"), (20000, 2048, "surface"), (2048, 1024, "uniform"),
+                                         (1024, 512, "uniform"), (512, 256, "uniform"), (300, 128, "uniform"),
+                                         (77, 77, "uniform"), (5000, 700, "surface"), (9000, 64, "uniform"),
+                                         (13000, 64, "uniform"), (17000, 64, "uniform"), (24000, 64, "uniform")])
+def test_fps_bit_exact(E, oracle, n, m, variant):
+    x = _cloud(100 + n, 2, n, variant)
+    want = oracle.furthest_point_sampling(x, m)
+    got = E.furthest_point_sampling(_dev(x), m).cpu()
+    assert torch.equal(got, want)
+
+
+def test_fps_large_n_fallback(E, oracle):
+    x = _cloud(7, 1, 50000)
+    want = oracle.furthest_point_sampling(x, 256)
+    got = E.furthest_point_sampling(_dev(x), 256).cpu()
+    assert torch.equal(got, want)
+
+
+def test_fps_adversarial_golden(E, golden_dir):
+    """duplicates (exact ties), near-origin skipped points, index 0 skipped."""
+    z = np.load(golden_dir + "/ops_small.npz")
+    for name in ("n1000", "n300", "n4096dup"):
+        x = torch.from_numpy(z[name + "/pts"])
+        m = z[name + "/fps"].shape[1]
+        got = E.furthest_point_sampling(_dev(x), m).cpu().numpy()
+        assert np.array_equal(got, z[name + "/fps"]), name
+
+
+def test_fps_all_ties_tree_order(E, oracle):
+    n = 1024
+    x = torch.zeros(2, n, 3)
+    x[:, :, 0] = 1.0
+    x[:, 0] = torch.tensor([0.0, 0.0, 1.0])
+    x[1, 5::7, 1] = 0.25           # second scene: two tied groups
+    want = oracle.furthest_point_sampling(x, 40)
+    got = E.furthest_point_sampling(_dev(x), 40).cpu()
+    assert torch.equal(got, want)
+    assert got[0, 1] == 512
+
+
+def test_fps_all_points_skipped(E, oracle):
+    x = torch.full((1, 600, 3), 0.01)
+    want = oracle.furthest_point_sampling(x, 16)
+    got = E.furthest_point_sampling(_dev(x), 16).cpu()
+    assert torch.equal(got, want) and not got.any()
+
+
+SA = [(20000, 2048, 0.04, 64), (2048, 1024, 0.1, 32), (1024, 512, 0.2, 16), (512, 256, 0.3, 16)]
+
+
+@pytest.mark.parametrize("n,m,r,ns", SA + [(3000, 333, 0.05, 100), (500, 7, 0.001, 8), (64, 64, 10.0, 64)])
+def test_ball_query_bit_exact(E, oracle, n, m, r, ns):
+    x = _cloud(200 + n, 2, n, "surface" if n == 3000 else "uniform")
+    c = x[:, torch.randperm(n, generator=torch.Generator().manual_seed(n))[:m]].contiguous()
+    if r == 0.001:
+        c = c + 0.5      # empty balls -> zero rows
+    want = oracle.ball_query(c, x, r, ns)
+    got = E.ball_query(_dev(c), _dev(x), r, ns).cpu()
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("n,m,hmax", [(20000, 1024, 0.01), (20000, 1024, 0.04), (4096, 100, 0.02), (50000, 256, 0.03)])
+def test_cylinder_query_bit_exact(E, oracle, model_oracle, n, m, hmax):
+    x = _cloud(300 + n, 2, n)
+    c = x[:, :m].contiguous()
+    rng = np.random.default_rng(n + m)
+    rot = model_oracle.viewpoint_to_matrix(torch.from_numpy(rng.standard_normal((2 * m, 3)).astype(np.float32)),
+                                           torch.zeros(2 * m)).view(2, m, 9).contiguous()
+    want = oracle.cylinder_query(c, x, rot, 0.05, -0.02, hmax, 64)
+    got = E.cylinder_query(_dev(c), _dev(x), _dev(rot), 0.05, -0.02, hmax, 64).cpu()
+    assert torch.equal(got, want)
+
+
+def test_group_gather_bit_exact(E, oracle):
+    g = torch.Generator().manual_seed(3)
+    for (b, c, n, npnt, ns) in [(2, 3, 20000, 2048, 64), (2, 128, 2048, 1024, 32), (1, 256, 512, 256, 16), (3, 5, 17, 3, 2)]:
+        f = torch.rand(b, c, n, generator=g)
+        idx = torch.randint(0, n, (b, npnt, ns), generator=g, dtype=torch.int32)
+        assert torch.equal(E.group_points(_dev(f), _dev(idx)).cpu(), oracle.group_points(f, idx))
+        gi = torch.randint(0, n, (b, npnt), generator=g, dtype=torch.int32)
+        assert torch.equal(E.gather_points(_dev(f), _dev(gi)).cpu(), oracle.gather_points(f, gi))
+
+
+def test_three_nn_interpolate_bit_exact(E, oracle):
+    for (n, m) in [(512, 256), (1024, 512), (100, 3), (70, 2500)]:
+        u, k = _cloud(1, 2, n), _cloud(2, 2, m)
+        k[:, m // 2:] = k[:, :m - m // 2]        # duplicates -> exact distance ties
+        d2w, iw = oracle.three_nn(u, k)
+        d2, i = E.three_nn(_dev(u), _dev(k))
+        assert torch.equal(i.cpu(), iw) and torch.equal(d2.cpu(), d2w)
+        w = torch.rand(2, n, 3)
+        f = torch.rand(2, 9, m)
+        assert torch.equal(E.three_interpolate(_dev(f), _dev(iw), _dev(w)).cpu(), oracle.three_interpolate(f, iw, w))
+
+
+def test_grad_ops(E, oracle):
+    g = torch.Generator().manual_seed(5)
+    f_n, npnt, ns = 40, 12, 4
+    idx = torch.randint(0, f_n, (2, npnt, ns), generator=g, dtype=torch.int32)
+    go = torch.rand(2, 6, npnt, ns, generator=g)
+    torch.testing.assert_close(E.group_points_grad(_dev(go), _dev(idx), f_n).cpu(), oracle.group_points_grad(go, idx, f_n),
+                               rtol=1e-5, atol=1e-5)   # float atomics: sum order differs
+    gi = torch.randint(0, f_n, (2, npnt), generator=g, dtype=torch.int32)
+    go2 = torch.rand(2, 6, npnt, generator=g)
+    torch.testing.assert_close(E.gather_points_grad(_dev(go2), _dev(gi), f_n).cpu(), oracle.gather_points_grad(go2, gi, f_n),
+                               rtol=1e-5, atol=1e-5)
+    i3 = torch.randint(0, f_n, (2, 15, 3), generator=g, dtype=torch.int32)
+    w = torch.rand(2, 15, 3, generator=g)
+    go3 = torch.rand(2, 6, 15, generator=g)
+    torch.testing.assert_close(E.three_interpolate_grad(_dev(go3), _dev(i3), _dev(w), f_n).cpu(),
+                               oracle.three_interpolate_grad(go3, i3, w, f_n), rtol=1e-5, atol=1e-5)
+
+
+def test_knn_bit_exact(oracle):
+    from graspnet_amd import knn_ext
+    rng = np.random.default_rng(0)
+    for (B, D, Nr, Nq, k) in [(1, 3, 300, 300, 1), (2, 3, 5000, 1024, 1), (2, 5, 64, 33, 7), (1, 3, 40, 10, 40), (1, 3, 700, 300, 3)]:
+        r = torch.from_numpy(rng.standard_normal((B, D, Nr)).astype(np.float32))
+        q = torch.from_numpy(rng.standard_normal((B, D, Nq)).astype(np.float32))
+        r[:, :, Nr // 2:] = r[:, :, :Nr - Nr // 2]
+        want = torch.zeros(B, k, Nq, dtype=torch.int64)
+        oracle.knn(r, q, want)
+        got = torch.zeros(B, k, Nq, dtype=torch.int64, device="cuda")
+        assert knn_ext.knn(r.cuda(), q.cuda(), got) == 1
+        assert torch.equal(got.cpu(), want)
+
+
+def test_error_behaviour_matches_reference(E):
+    x = torch.rand(1, 10, 3)
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        E.furthest_point_sampling(x, 4)
+    with pytest.raises(RuntimeError, match="must be a contiguous tensor"):
+        E.furthest_point_sampling(torch.rand(1, 3, 10).cuda().transpose(1, 2), 4)
+    with pytest.raises(RuntimeError, match="must be a float tensor"):
+        E.ball_query(x.cuda().double(), x.cuda(), 0.1, 4)
+    with pytest.raises(RuntimeError, match="must be an int tensor"):
+        E.group_points(torch.rand(1, 3, 10).cuda(), torch.zeros(1, 2, 2, dtype=torch.int64).cuda())
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        E.ball_query(x.cuda(), x, 0.1, 4)

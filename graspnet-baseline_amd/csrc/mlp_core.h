@@ -1,0 +1,245 @@
+// mlp_core.h -- fp32 MFMA building blocks for the fused "gather -> shared MLP -> pool" kernels.
+//
+// Replaces, in fused form, the reference's SharedMLP stacks
+// (pointnet2/pytorch_utils.py:11-120: conv1x1 -> BatchNorm(eval) -> ReLU, executed there as
+// separate cuDNN / elementwise kernels with every intermediate written to HBM).
+//
+// Orientation.  Activations are kept POSITION-major ("channels last"): a tile is X[TP][C] in LDS.
+// One layer is  Y[TP][COUT] = act( X[TP][CIN] * W^T + bias )  with BN folded into W / bias on the
+// host.  It is computed with v_mfma_f32_32x32x2_f32 (exact fp32, CDNA4):
+//     A operand = activations  (row = position  = lane&31, k = lane>>5)
+//     B operand = weights      (col = out chan  = lane&31, k = lane>>5)
+//     C/D       = 32 positions x 32 channels:  col(chan) = lane&31,
+//                 row(pos) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+// so the max-pool over a group's positions is an in-lane max over accumulator registers (plus one
+// lane^32 exchange), and the next layer's A operand is read back from LDS as contiguous float4s.
+//
+// k mapping.  A lane reads 4 consecutive channels X[pos][kb*8 + 4*(lane>>5) + s], s=0..3, with one
+// ds_read_b128 and feeds MFMA step s with element s; the host packs the weights in exactly that
+// fragment order (graspnet_amd/weights.py: pack_fragments) so a B fragment is one coalesced
+// 16-byte-per-lane load:   Wp[nt][kb][lane][s] = W[nt*32 + (lane&31)][kb*8 + 4*(lane>>5) + s].
+//
+// Weights stay STATIONARY in registers (gfx950: 512 unified VGPR/AGPR per lane at one wave per
+// SIMD): a workgroup of 4 waves is persistent over many position tiles, each wave owns a slice of
+// the output channels of every layer and streams position tiles from LDS past its weights, so the
+// inner loop touches HBM/L2 for nothing and LDS only for the A operand (one b128 read per 4*NTW
+// MFMAs).
+//
+// LDS row stride is C+4 floats: (C+4)/4 is odd, which makes the 16-lane groups of ds_read_b128
+// (MI355X guide, LDS table) hit 16 distinct 16-byte slots -> conflict-free A reads.
+#pragma once
+#include "gn_common.h"
+
+namespace gn {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int MLP_THREADS = 256;  // 4 waves, one per SIMD
+
+__host__ __device__ constexpr int lds_stride(int c) { return c + 4; }
+__host__ __device__ constexpr int wn_for(int coutp) { return (coutp / 32) >= 4 ? 4 : (coutp / 32); }
+__host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// ---- one layer's weight slice of this wave, resident in registers
+template <int CINP, int COUTP>
+struct LayerW {
+  static_assert(CINP % 8 == 0 && COUTP % 32 == 0, "pad CIN to 8 and COUT to 32");
+  static constexpr int NT = COUTP / 32;
+  static constexpr int WN = wn_for(COUTP);
+  static constexpr int WM = 4 / WN;
+  static_assert(NT % WN == 0, "N tiles must divide over the waves");
+  static constexpr int NTW = NT / WN;
+  static constexpr int KB = CINP / 8;
+  f32x4 b[NTW][KB];
+  float bias[NTW];
+
+  __device__ __forceinline__ void load(const float *__restrict__ wp, const float *__restrict__ bp, int wave,
+                                       int lane) {
+    const int wn = wave % WN;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      const int nt = wn * NTW + i;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+        b[i][kb] = *reinterpret_cast<const f32x4 *>(wp + ((size_t)(nt * KB + kb) * 64 + lane) * 4);
+      bias[i] = bp[nt * 32 + (lane & 31)];
+    }
+  }
+};
+
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ---- epilogues ------------------------------------------------------------------------------
+// write act(acc) to an LDS activation tile Y[TP][ys]; only channels < ncols exist in Y
+template <bool RELU>
+struct StoreLds {
+  float *ys;
+  int stride;
+  int ncols;
+  int lane;
+  __device__ __forceinline__ void begin() {}
+  __device__ __forceinline__ void operator()(int mt, int nt, int /*i*/, const f32x16 &acc) {
+    const int col = nt * 32 + (lane & 31);
+    if (col < ncols) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = RELU ? fmaxf(acc[r], 0.f) : acc[r];
+        ys[(mt * 32 + acc_row(r, lane)) * stride + col] = v;
+      }
+    }
+  }
+};
+
+// write act(acc) to global, row-major out[row0 + pos][ldo], channels < ncols, rows < nrows
+template <bool RELU>
+struct StoreGlobal {
+  float *out;   // already offset to the tile's first row
+  int ldo;
+  int ncols;
+  int nrows;    // valid rows in this tile
+  int lane;
+  __device__ __forceinline__ void begin() {}
+  __device__ __forceinline__ void operator()(int mt, int nt, int /*i*/, const f32x16 &acc) {
+    const int col = nt * 32 + (lane & 31);
+    if (col < ncols) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + acc_row(r, lane);
+        const float v = RELU ? fmaxf(acc[r], 0.f) : acc[r];
+        if (row < nrows) out[(size_t)row * ldo + col] = v;
+      }
+    }
+  }
+};
+
+__device__ __forceinline__ float xhalf_max(float v, int lane) {
+  const float o = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, v)));
+  return fmaxf(v, o);
+}
+
+// ReLU + max over each group of NS consecutive positions -> out[group][ldo] (channels-last)
+// (F.max_pool2d(kernel=[1,nsample]) of pointnet2_modules.py:255 / modules.py:137)
+template <int NS, int NTW>
+struct PoolGlobal {
+  float *out;  // offset to the tile's first group
+  int ldo;
+  int lane;
+  float hold[NTW];
+  __device__ __forceinline__ void begin() {}
+  __device__ __forceinline__ void operator()(int mt, int nt, int i, const f32x16 &acc) {
+    const int col = nt * 32 + (lane & 31);
+    if (NS == 16) {
+      float v0 = acc[0], v1 = acc[8];
+#pragma unroll
+      for (int r = 1; r < 8; ++r) { v0 = fmaxf(v0, acc[r]); v1 = fmaxf(v1, acc[8 + r]); }
+      v0 = xhalf_max(v0, lane);
+      v1 = xhalf_max(v1, lane);
+      if (lane < 32) {
+        out[(size_t)(mt * 2 + 0) * ldo + col] = fmaxf(v0, 0.f);
+        out[(size_t)(mt * 2 + 1) * ldo + col] = fmaxf(v1, 0.f);
+      }
+    } else {
+      float v = acc[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) v = fmaxf(v, acc[r]);
+      v = xhalf_max(v, lane);
+      if (NS == 32) {
+        if (lane < 32) out[(size_t)mt * ldo + col] = fmaxf(v, 0.f);
+      } else {  // NS == 64: two consecutive M tiles form a group (requires WM == 1)
+        static_assert(NS == 16 || NS == 32 || NS == 64, "unsupported nsample");
+        if ((mt & 1) == 0) {
+          hold[i] = v;
+        } else {
+          v = fmaxf(v, hold[i]);
+          if (lane < 32) out[(size_t)(mt >> 1) * ldo + col] = fmaxf(v, 0.f);
+        }
+      }
+    }
+  }
+};
+
+// ---- one layer over a TP-position LDS tile, weights resident --------------------------------
+template <int TP, int CINP, int COUTP, class Epi>
+__device__ __forceinline__ void run_layer(const LayerW<CINP, COUTP> &w, const float *__restrict__ xs, int wave,
+                                          int lane, Epi &epi) {
+  using LW = LayerW<CINP, COUTP>;
+  constexpr int XS = lds_stride(CINP);
+  const int wm = wave / LW::WN;
+  const int wn = wave % LW::WN;
+  for (int mt = wm; mt < TP / 32; mt += LW::WM) {
+    f32x16 acc[LW::NTW];
+#pragma unroll
+    for (int i = 0; i < LW::NTW; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = w.bias[i];
+    const float *xr = xs + (mt * 32 + (lane & 31)) * XS + 4 * (lane >> 5);
+#pragma unroll
+    for (int kb = 0; kb < LW::KB; ++kb) {
+      const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + kb * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < LW::NTW; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w.b[i][kb][s], acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < LW::NTW; ++i) epi(mt, wn * LW::NTW + i, i, acc[i]);
+  }
+}
+
+// ---- one layer, weights streamed from L2 in K chunks (for layers too wide to keep resident) ---
+// accumulators for all of this wave's tiles persist across the K chunks.
+template <int TP, int CINP, int COUTP, int KC, class Epi, int XS = lds_stride(CINP)>
+__device__ __forceinline__ void run_layer_stream(const float *__restrict__ wp, const float *__restrict__ bp,
+                                                 const float *__restrict__ xs, int wave, int lane, Epi &epi) {
+  static_assert(CINP % KC == 0 && KC % 8 == 0, "bad K chunk");
+  constexpr int NT = COUTP / 32;
+  constexpr int WN = wn_for(COUTP);
+  constexpr int WM = 4 / WN;
+  static_assert(NT % WN == 0, "N tiles must divide over the waves");
+  constexpr int NTW = NT / WN;
+  constexpr int MT = TP / 32;
+  static_assert(MT % WM == 0, "M tiles must divide over the waves");
+  constexpr int MTW = MT / WM;
+  constexpr int KB = CINP / 8, KBC = KC / 8;
+  const int wm = wave / WN, wn = wave % WN;
+  f32x16 acc[MTW][NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    const float bv = bp[(wn * NTW + i) * 32 + (lane & 31)];
+#pragma unroll
+    for (int mi = 0; mi < MTW; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][i][r] = bv;
+  }
+#pragma unroll 1
+  for (int kc = 0; kc < KB; kc += KBC) {
+    f32x4 b[NTW][KBC];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+      for (int kb = 0; kb < KBC; ++kb)
+        b[i][kb] = *reinterpret_cast<const f32x4 *>(wp + ((size_t)((wn * NTW + i) * KB + kc + kb) * 64 + lane) * 4);
+#pragma unroll
+    for (int mi = 0; mi < MTW; ++mi) {
+      const int mt = wm * MTW + mi;
+      const float *xr = xs + (mt * 32 + (lane & 31)) * XS + 4 * (lane >> 5) + kc * 8;
+#pragma unroll
+      for (int kb = 0; kb < KBC; ++kb) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + kb * 8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < NTW; ++i)
+            acc[mi][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[i][kb][s], acc[mi][i], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < MTW; ++mi)
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) epi(wm * MTW + mi, wn * NTW + i, i, acc[mi][i]);
+}
+
+}  // namespace gn

@@ -1,0 +1,246 @@
+// mlp_group.hip -- fused "group -> centre/normalise (or rotate) -> SharedMLP x3 -> max-pool" kernels.
+//
+// Set-abstraction tail of PointnetSAModuleVotes.forward (pointnet2/pointnet2_modules.py:243-257 with
+// QueryAndGroup.forward, pointnet2/pointnet2_utils.py:344-355) and CloudCrop.forward
+// (models/modules.py:127-140 with CylinderQueryAndGroup.forward, pointnet2_utils.py:521-530).
+// The reference materialises the grouped tensor (B,3+C,np,ns), three conv/BN/ReLU activations and
+// the pooled result in HBM (2.1 GB for CloudCrop at batch 8); here a persistent workgroup gathers a
+// tile of TP neighbour rows straight into LDS, runs the three layers on fp32 MFMA with the weights
+// resident in registers (mlp_core.h) and writes only the pooled (group, C3) rows.
+#include "mlp_core.h"
+
+namespace gn {
+
+struct Mlp3Weights {
+  const float *w1, *b1, *w2, *b2, *w3, *b3;  // fragment-packed weights / padded bias per layer
+};
+
+// ---- loaders: fill X0[TP][CIN0+4] in LDS ------------------------------------------------------
+// SA rows: [ features of neighbour (C) | (xyz[src]-centre)/radius (3) | 0-pad to 8 ]
+// (the host permutes the first layer's input columns accordingly: the reference concatenates xyz
+//  first, pointnet2_utils.py:353)
+template <int C, int TP, int NS>
+__device__ __forceinline__ void load_sa_tile(float *__restrict__ xs, const float *__restrict__ xyz,
+                                             const float *__restrict__ feat, const float *__restrict__ cxyz,
+                                             const int32_t *__restrict__ idx, float radius, int tid) {
+  constexpr int XS = lds_stride(C + 8);
+  if (C > 0) {
+    constexpr int Q = C / 4;  // float4 per row
+    for (int e = tid; e < TP * Q; e += MLP_THREADS) {
+      const int row = e / Q, c4 = e - row * Q;
+      const int src = idx[row];
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(feat + (size_t)src * C + c4 * 4);
+      *reinterpret_cast<f32x4 *>(xs + row * XS + c4 * 4) = v;
+    }
+  }
+  for (int p = tid; p < TP; p += MLP_THREADS) {
+    const int src = idx[p];
+    const float *c = cxyz + (p / NS) * 3;
+    // grouped_xyz -= new_xyz; grouped_xyz /= radius   (pointnet2_utils.py:346-348)
+    f32x4 v;
+    v[0] = (xyz[src * 3 + 0] - c[0]) / radius;
+    v[1] = (xyz[src * 3 + 1] - c[1]) / radius;
+    v[2] = (xyz[src * 3 + 2] - c[2]) / radius;
+    v[3] = 0.f;
+    *reinterpret_cast<f32x4 *>(xs + p * XS + C) = v;
+    *reinterpret_cast<f32x4 *>(xs + p * XS + C + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+template <int CIN0, int C1, int C2, int TP>
+__host__ __device__ constexpr int group_mlp_lds_floats() {
+  return cmax(TP * lds_stride(CIN0), TP * lds_stride(C2)) + TP * lds_stride(C1);
+}
+
+// ---- set abstraction ---------------------------------------------------------------------------
+template <int C, int C1, int C2, int C3, int NS, int TP>
+__global__ __launch_bounds__(MLP_THREADS) void sa_mlp_kernel(const float *__restrict__ xyz, int n,
+                                                             const float *__restrict__ feat,
+                                                             const float *__restrict__ new_xyz,
+                                                             const int32_t *__restrict__ idx, int np, int ntiles,
+                                                             float radius, Mlp3Weights W, float *__restrict__ out) {
+  constexpr int CIN0 = C + 8;
+  constexpr int GPT = TP / NS;  // groups per tile
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *bufA = smem;
+  float *bufB = smem + cmax(TP * lds_stride(CIN0), TP * lds_stride(C2));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  LayerW<CIN0, C1> w1;
+  LayerW<C1, C2> w2;
+  LayerW<C2, C3> w3;
+  w1.load(W.w1, W.b1, wave, lane);
+  w2.load(W.w2, W.b2, wave, lane);
+  w3.load(W.w3, W.b3, wave, lane);
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int g0 = tile * GPT;   // first (flat) group of the tile; np % GPT == 0 so it stays in one cloud
+    const int b = g0 / np;
+    load_sa_tile<C, TP, NS>(bufA, xyz + (size_t)b * n * 3, C > 0 ? feat + (size_t)b * n * C : nullptr,
+                            new_xyz + (size_t)g0 * 3, idx + (size_t)g0 * NS, radius, tid);
+    __syncthreads();
+    StoreLds<true> e1{bufB, lds_stride(C1), C1, lane};
+    run_layer<TP, CIN0, C1>(w1, bufA, wave, lane, e1);
+    __syncthreads();
+    StoreLds<true> e2{bufA, lds_stride(C2), C2, lane};
+    run_layer<TP, C1, C2>(w2, bufB, wave, lane, e2);
+    __syncthreads();
+    PoolGlobal<NS, LayerW<C2, C3>::NTW> e3{out + (size_t)g0 * C3, C3, lane, {}};
+    run_layer<TP, C2, C3>(w3, bufA, wave, lane, e3);
+    __syncthreads();
+  }
+}
+
+// ---- cloud crop --------------------------------------------------------------------------------
+template <int C1, int C2, int C3, int NS, int ND, int TP>
+__global__ __launch_bounds__(MLP_THREADS) void crop_mlp_kernel(const float *__restrict__ xyz, int n,
+                                                               const float *__restrict__ seed,
+                                                               const float *__restrict__ rot,
+                                                               const int32_t *__restrict__ idx, int m, int ntiles,
+                                                               Mlp3Weights W, float *__restrict__ out) {
+  constexpr int CIN0 = 8;
+  constexpr int GPT = TP / NS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *bufA = smem;
+  float *bufB = smem + cmax(TP * lds_stride(CIN0), TP * lds_stride(C2));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  LayerW<CIN0, C1> w1;
+  LayerW<C1, C2> w2;
+  LayerW<C2, C3> w3;
+  w1.load(W.w1, W.b1, wave, lane);
+  w2.load(W.w2, W.b2, wave, lane);
+  w3.load(W.w3, W.b3, wave, lane);
+
+  const int gpc = m * ND;  // groups per cloud
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int g0 = tile * GPT;
+    const int b = g0 / gpc;
+    const int gl = g0 - b * gpc;  // first group within the cloud
+    // tile groups are consecutive [seed][depth] entries of one cloud; pass seed/rot bases of the
+    // cloud and a local group offset folded into the row index
+    const float *seed_b = seed + (size_t)b * m * 3;
+    const float *rot_b = rot + (size_t)b * m * 9;
+    {
+      constexpr int XS = lds_stride(8);
+      const int32_t *ix = idx + (size_t)g0 * NS;
+      const float *px = xyz + (size_t)b * n * 3;
+      for (int p = tid; p < TP; p += MLP_THREADS) {
+        const int src = ix[p];
+        const int s = (gl + p / NS) / ND;
+        const float *c = seed_b + s * 3;
+        const float *r = rot_b + s * 9;
+        const float x = px[src * 3 + 0] - c[0];
+        const float y = px[src * 3 + 1] - c[1];
+        const float z = px[src * 3 + 2] - c[2];
+        f32x4 v;
+        v[0] = x * r[0] + y * r[3] + z * r[6];
+        v[1] = x * r[1] + y * r[4] + z * r[7];
+        v[2] = x * r[2] + y * r[5] + z * r[8];
+        v[3] = 0.f;
+        *reinterpret_cast<f32x4 *>(bufA + p * XS) = v;
+        *reinterpret_cast<f32x4 *>(bufA + p * XS + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    __syncthreads();
+    StoreLds<true> e1{bufB, lds_stride(C1), C1, lane};
+    run_layer<TP, CIN0, C1>(w1, bufA, wave, lane, e1);
+    __syncthreads();
+    StoreLds<true> e2{bufA, lds_stride(C2), C2, lane};
+    run_layer<TP, C1, C2>(w2, bufB, wave, lane, e2);
+    __syncthreads();
+    PoolGlobal<NS, LayerW<C2, C3>::NTW> e3{out + (size_t)g0 * C3, C3, lane, {}};
+    run_layer<TP, C2, C3>(w3, bufA, wave, lane, e3);
+    __syncthreads();
+  }
+}
+
+static int persistent_grid(int ntiles) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return ntiles < cus ? ntiles : cus;
+}
+
+template <class K>
+static int set_lds(K kernel, size_t bytes, const char *name) {
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)bytes) != hipSuccess) {
+    set_error("%s: cannot reserve %zu bytes of LDS", name, bytes);
+    return GN_ERR_LAUNCH;
+  }
+  return GN_OK;
+}
+
+template <int C, int C1, int C2, int C3, int NS, int TP>
+static int launch_sa(const float *xyz, const float *feat, const float *new_xyz, const int32_t *idx, int b, int n,
+                     int np, float radius, const Mlp3Weights &W, float *out, hipStream_t s) {
+  GN_REQUIRE(np % (TP / NS) == 0, "sa_group_mlp_pool: npoint must be a multiple of %d", TP / NS);
+  const int ntiles = (int)((long)b * np / (TP / NS));
+  constexpr size_t lds = sizeof(float) * group_mlp_lds_floats<C + 8, C1, C2, TP>();
+  auto k = sa_mlp_kernel<C, C1, C2, C3, NS, TP>;
+  int rc = set_lds(k, lds, "sa_group_mlp_pool");
+  if (rc) return rc;
+  hipLaunchKernelGGL(k, dim3(persistent_grid(ntiles)), dim3(MLP_THREADS), lds, s, xyz, n, feat, new_xyz, idx, np,
+                     ntiles, radius, W, out);
+  GN_CHECK_LAUNCH("sa_group_mlp_pool");
+  return GN_OK;
+}
+
+}  // namespace gn
+
+using namespace gn;
+
+extern "C" int gn_sa_group_mlp_pool(const float *xyz, const float *feat, const float *new_xyz, const int32_t *idx,
+                                    int b, int n, int np, int ns, int c, float radius, const int *mlp,
+                                    const float *const *wpacked, const float *const *bias, float *out,
+                                    gn_stream_t stream) {
+  GN_REQUIRE(b >= 0 && n > 0 && np > 0 && ns > 0 && c >= 0, "sa_group_mlp_pool: bad sizes");
+  if (b == 0) return GN_OK;
+  GN_REQUIRE(xyz && new_xyz && idx && mlp && wpacked && bias && out && (c == 0 || feat),
+             "sa_group_mlp_pool: null pointer");
+  GN_REQUIRE((long)n * cmax(c, 3) < 0x7fffffffL, "sa_group_mlp_pool: n*c too large");
+  const Mlp3Weights W{wpacked[0], bias[0], wpacked[1], bias[1], wpacked[2], bias[2]};
+  hipStream_t s = as_stream(stream);
+  const int c1 = mlp[0], c2 = mlp[1], c3 = mlp[2];
+  // configurations of models/backbone.py:30-64
+  if (c == 0 && c1 == 64 && c2 == 64 && c3 == 128 && ns == 64)
+    return launch_sa<0, 64, 64, 128, 64, 128>(xyz, feat, new_xyz, idx, b, n, np, radius, W, out, s);
+  if (c == 128 && c1 == 128 && c2 == 128 && c3 == 256 && ns == 32)
+    return launch_sa<128, 128, 128, 256, 32, 128>(xyz, feat, new_xyz, idx, b, n, np, radius, W, out, s);
+  if (c == 256 && c1 == 128 && c2 == 128 && c3 == 256 && ns == 16)
+    return launch_sa<256, 128, 128, 256, 16, 64>(xyz, feat, new_xyz, idx, b, n, np, radius, W, out, s);
+  set_error("sa_group_mlp_pool: unsupported configuration C=%d mlp=[%d,%d,%d] nsample=%d", c, c1, c2, c3, ns);
+  return GN_ERR_INVALID_ARG;
+}
+
+extern "C" int gn_crop_group_mlp_pool(const float *xyz, const float *seed_xyz, const float *rot, const int32_t *idx,
+                                      int b, int n, int m, int ndepth, int ns, const int *mlp,
+                                      const float *const *wpacked, const float *const *bias, float *out,
+                                      gn_stream_t stream) {
+  GN_REQUIRE(b >= 0 && n > 0 && m > 0, "crop_group_mlp_pool: bad sizes");
+  if (b == 0) return GN_OK;
+  GN_REQUIRE(xyz && seed_xyz && rot && idx && mlp && wpacked && bias && out, "crop_group_mlp_pool: null pointer");
+  GN_REQUIRE((long)n * 3 < 0x7fffffffL, "crop_group_mlp_pool: n too large");
+  if (!(ndepth == 4 && ns == 64 && mlp[0] == 64 && mlp[1] == 128 && mlp[2] == 256)) {
+    set_error("crop_group_mlp_pool: unsupported configuration depth=%d nsample=%d mlp=[%d,%d,%d]", ndepth, ns, mlp[0],
+              mlp[1], mlp[2]);
+    return GN_ERR_INVALID_ARG;
+  }
+  constexpr int TP = 128, NS = 64, ND = 4;
+  GN_REQUIRE((m * ND) % (TP / NS) == 0, "crop_group_mlp_pool: bad seed count");
+  const Mlp3Weights W{wpacked[0], bias[0], wpacked[1], bias[1], wpacked[2], bias[2]};
+  const int ntiles = (int)((long)b * m * ND / (TP / NS));
+  constexpr size_t lds = sizeof(float) * group_mlp_lds_floats<8, 64, 128, TP>();
+  auto k = crop_mlp_kernel<64, 128, 256, NS, ND, TP>;
+  int rc = set_lds(k, lds, "crop_group_mlp_pool");
+  if (rc) return rc;
+  hipLaunchKernelGGL(k, dim3(persistent_grid(ntiles)), dim3(MLP_THREADS), lds, as_stream(stream), xyz, n, seed_xyz,
+                     rot, idx, m, ntiles, W, out);
+  GN_CHECK_LAUNCH("crop_group_mlp_pool");
+  return GN_OK;
+}

@@ -70,6 +70,65 @@ __global__ __launch_bounds__(QUERY_WAVES * 64) void query_kernel(
     for (int l = cnt + lane; l < nsample; l += 64) row[l] = first;
 }
 
+// CloudCrop runs four cylinder queries that differ only in hmax (models/modules.py:103-106).
+// One scan serves all ND depths: the radial / hmin tests are shared, each depth keeps its own
+// "first nsample in index order" list, padding and zero-row rule.  idx: (B, M, ND, nsample).
+template <int ND>
+__global__ __launch_bounds__(QUERY_WAVES * 64) void cylinder_multi_kernel(
+    const float *__restrict__ new_xyz, const float *__restrict__ xyz, const float *__restrict__ rot, int n, int m,
+    float radius, float hmin, float hmax0, float hmax1, float hmax2, float hmax3, int nsample,
+    int32_t *__restrict__ idx) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * QUERY_WAVES + (threadIdx.x >> 6);
+  if (j >= m) return;
+  xyz += (size_t)b * n * 3;
+  const float *c = new_xyz + ((size_t)b * m + j) * 3;
+  const float *r = rot + ((size_t)b * m + j) * 9;
+  int32_t *row = idx + ((size_t)b * m + j) * ND * nsample;
+  const float radius2 = radius * radius;
+  const float cx = c[0], cy = c[1], cz = c[2];
+  const float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7], r8 = r[8];
+  const float hmax[4] = {hmax0, hmax1, hmax2, hmax3};
+  int cnt[ND], first[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d) { cnt[d] = 0; first[d] = 0; }
+  for (int k0 = 0; k0 < n; k0 += 64) {
+    bool done = true;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) done = done && (cnt[d] >= nsample);
+    if (done) break;
+    const int k = k0 + lane;
+    bool base = false;
+    float x_rot = 0.f;
+    if (k < n) {
+      const float x = xyz[k * 3 + 0] - cx, y = xyz[k * 3 + 1] - cy, z = xyz[k * 3 + 2] - cz;
+      x_rot = r0 * x + r3 * y + r6 * z;
+      const float y_rot = r1 * x + r4 * y + r7 * z;
+      const float z_rot = r2 * x + r5 * y + r8 * z;
+      const float d2 = y_rot * y_rot + z_rot * z_rot;
+      base = d2 < radius2 && x_rot > hmin;
+    }
+    if (!__ballot(base)) continue;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+      const bool hit = base && x_rot < hmax[d];
+      const unsigned long long mask = __ballot(hit);
+      if (mask && cnt[d] < nsample) {
+        if (cnt[d] == 0) first[d] = k0 + __ffsll((long long)mask) - 1;
+        const int slot = cnt[d] + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        if (hit && slot < nsample) row[d * nsample + slot] = k;
+        cnt[d] += __popcll(mask);
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < ND; ++d)
+    if (cnt[d] < nsample)
+      for (int l = cnt[d] + lane; l < nsample; l += 64) row[d * nsample + l] = first[d];
+}
+
 template <bool CYL>
 static int launch_query(const float *new_xyz, const float *xyz, const float *rot, int b, int n, int m,
                         float radius, float hmin, float hmax, int nsample, int32_t *idx,
@@ -99,4 +158,21 @@ extern "C" int gn_cylinder_query(const float *new_xyz, const float *xyz, const f
                                  gn_stream_t stream) {
   return gn::launch_query<true>(new_xyz, xyz, rot, b, n, m, radius, hmin, hmax, nsample, idx, stream,
                                 "cylinder_query");
+}
+
+extern "C" int gn_cylinder_query_multi(const float *new_xyz, const float *xyz, const float *rot, int b, int n, int m,
+                                       float radius, float hmin, const float *hmax_host, int ndepth, int nsample,
+                                       int32_t *idx, gn_stream_t stream) {
+  using namespace gn;
+  GN_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0, "cylinder_query_multi: bad sizes");
+  if (b == 0 || m == 0 || nsample == 0) return GN_OK;
+  GN_REQUIRE(new_xyz && xyz && rot && idx && hmax_host, "cylinder_query_multi: null pointer");
+  GN_REQUIRE(ndepth == 4, "cylinder_query_multi: only 4 depths supported (got %d)", ndepth);
+  GN_REQUIRE(b <= 65535, "cylinder_query_multi: batch > 65535 unsupported");
+  GN_REQUIRE((long)n * 3 < 0x7fffffffL, "cylinder_query_multi: n too large");
+  dim3 grid((m + QUERY_WAVES - 1) / QUERY_WAVES, b);
+  hipLaunchKernelGGL((cylinder_multi_kernel<4>), grid, dim3(QUERY_WAVES * 64), 0, as_stream(stream), new_xyz, xyz,
+                     rot, n, m, radius, hmin, hmax_host[0], hmax_host[1], hmax_host[2], hmax_host[3], nsample, idx);
+  GN_CHECK_LAUNCH("cylinder_query_multi");
+  return GN_OK;
 }

@@ -33,6 +33,25 @@ SIGNATURES = {
     "gn_three_interpolate": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
     "gn_three_interpolate_grad": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
     "gn_knn": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "gn_cylinder_query_multi": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float,
+                                         ctypes.POINTER(_c_float), _c_int, _c_int, _c_void_p, _c_void_p]),
+    "gn_sa_group_mlp_pool": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                      _c_float, ctypes.POINTER(_c_int), ctypes.POINTER(_c_void_p),
+                                      ctypes.POINTER(_c_void_p), _c_void_p, _c_void_p]),
+    "gn_crop_group_mlp_pool": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                        ctypes.POINTER(_c_int), ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
+                                        _c_void_p, _c_void_p]),
+    "gn_fp_interp_mlp": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                  ctypes.POINTER(_c_int), ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
+                                  _c_void_p, _c_void_p]),
+    "gn_approach_mlp": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
+                                 _c_void_p, _c_void_p]),
+    "gn_heads_mlp": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
+                              _c_void_p, _c_void_p]),
+    "gn_approach_post": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                  _c_void_p, _c_void_p, _c_void_p]),
+    "gn_pred_decode": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
+                                _c_int, _c_void_p, _c_void_p, _c_void_p]),
 }
 
 

@@ -1,0 +1,276 @@
+"""GraspNet inference on MI355X: host-side mirror of the reference model API.
+
+Same constructor arguments, `forward(end_points) -> end_points` keys/shapes and
+`pred_decode(end_points)` result as models/graspnet.py:63-134 of the reference, executed as ~25
+hand-written gfx950 kernels behind the C ABI (include/graspnet_hip.h).  torch is used for device
+memory and streams only.
+
+Differences a caller can observe:
+  * inference only (is_training=True is refused: label generation / losses are out of scope);
+  * feature tensors in `end_points` have the reference's SHAPES but are strided views of
+    position-major buffers (call .contiguous() if a dense (B,C,N) layout is needed);
+  * weights are given as a state-dict with the reference's key layout via load_state_dict().
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from . import geometry, weights
+
+# models/backbone.py:30-64 : (npoint, radius, nsample, C_in_features, mlp)
+SA_CFG = (
+    (2048, 0.04, 64, 0, (64, 64, 128)),
+    (1024, 0.1, 32, 128, (128, 128, 256)),
+    (512, 0.2, 16, 256, (128, 128, 256)),
+    (256, 0.3, 16, 256, (128, 128, 256)),
+)
+GRASP_ROW = 17   # [score,width,height,depth,R(9),center(3),obj_id]  models/graspnet.py:131-133
+
+
+def _ci(*vals):
+    return (ctypes.c_int * len(vals))(*vals)
+
+
+class GraspNet:
+    """Drop-in for `models.graspnet.GraspNet` (inference)."""
+
+    def __init__(self, input_feature_dim=0, num_view=300, num_angle=12, num_depth=4, cylinder_radius=0.05,
+                 hmin=-0.02, hmax_list=(0.01, 0.02, 0.03, 0.04), is_training=False, device="cuda"):
+        if is_training:
+            raise NotImplementedError("graspnet_amd.GraspNet is an inference path (is_training=False)")
+        if input_feature_dim != 0:
+            raise NotImplementedError("input_feature_dim != 0 is not used by the reference model")
+        if num_depth != 4 or len(hmax_list) != 4 or num_angle != 12 or num_view != 300:
+            raise NotImplementedError("only the reference configuration (300 views, 12 angles, 4 depths) is built")
+        self.num_view, self.num_angle, self.num_depth = num_view, num_angle, num_depth
+        self.cylinder_radius, self.hmin = float(cylinder_radius), float(hmin)
+        self.hmax = (ctypes.c_float * 4)(*[float(h) for h in hmax_list])
+        self.crop_nsample = 64                     # models/graspnet.py:44
+        self.is_training = False
+        self.device = torch.device(device)
+        self._packed = None
+        self._tables = None
+        self._sd = None
+        self.timing = None        # set to {} to collect (start,end) HIP events per kernel launch
+
+    def _run(self, name, status_fn):
+        """Issue one C-ABI call; when self.timing is a dict, bracket it with events on the launch stream."""
+        if self.timing is None:
+            L.check(status_fn(), name)
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        L.check(status_fn(), name)
+        b.record()
+        self.timing.setdefault(name, []).append((a, b))
+
+    # ---- nn.Module-like surface used by the reference's callers (demo.py:get_net etc.)
+    def load_state_dict(self, state_dict, strict=True):
+        want = _expected_keys()
+        missing = [k for k in want if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in want]
+        if strict and (missing or unexpected):
+            raise RuntimeError("Error(s) in loading state_dict for GraspNet: missing %s unexpected %s"
+                               % (missing[:5], unexpected[:5]))
+        self._sd = {k: v.detach().clone() for k, v in state_dict.items()}
+        self._build()
+        return self
+
+    def state_dict(self):
+        return dict(self._sd or {})
+
+    def to(self, device):
+        self.device = torch.device(device)
+        if self._sd is not None:
+            self._build()
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("training is out of scope")
+        return self
+
+    def _build(self):
+        if self.device.type != "cuda":
+            raise RuntimeError("graspnet_amd.GraspNet needs a GPU device (there is no CPU path)")
+        L.lib()   # fail loudly here if the HIP library is missing
+        self._packed = weights.prepare(self._sd, self.device, self.num_view, self.num_angle)
+        v, vr, dr = geometry.build_tables(self.num_view, self.num_angle)
+        self._tables = (v.to(self.device), vr.to(self.device), dr.to(self.device))
+
+    def __call__(self, end_points):
+        return self.forward(end_points)
+
+    # ---- the hot path -----------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, end_points):
+        if self._packed is None:
+            raise RuntimeError("GraspNet.forward: load_state_dict() first")
+        pc = end_points["point_clouds"]
+        if not pc.is_cuda:
+            raise RuntimeError("CPU not supported")
+        if pc.dtype != torch.float32 or pc.dim() != 3 or pc.size(-1) < 3:
+            raise RuntimeError("point_clouds must be a (B,N,3) float tensor")
+        lib = L.lib()
+        dev = pc.device
+        B, N = pc.size(0), pc.size(1)
+        f32, i32 = torch.float32, torch.int32
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            xyz = pc[..., 0:3].contiguous()                      # backbone.py:69-75 _break_up_pc
+            end_points["input_xyz"] = xyz
+            end_points["input_features"] = None
+
+            # ---- 4 set-abstraction levels (backbone.py:105-121)
+            lv_xyz, lv_feat, lv_n, lv_inds = xyz, None, N, []
+            feats = []
+            for li, (npoint, radius, nsample, c, mlp) in enumerate(SA_CFG):
+                inds = torch.empty((B, npoint), dtype=i32, device=dev)
+                new_xyz = torch.empty((B, npoint, 3), dtype=f32, device=dev)
+                wsb = lib.gn_fps_workspace_bytes(B, lv_n)
+                ws = torch.empty((wsb,), dtype=torch.uint8, device=dev) if wsb else None
+                self._run("furthest_point_sampling[%d]" % (li + 1), lambda: lib.gn_furthest_point_sampling(lv_xyz.data_ptr(), B, lv_n, npoint, L.ptr(ws), inds.data_ptr(),
+                                                       new_xyz.data_ptr(), st))
+                idx = torch.empty((B, npoint, nsample), dtype=i32, device=dev)
+                self._run("ball_query[%d]" % (li + 1), lambda: lib.gn_ball_query(new_xyz.data_ptr(), lv_xyz.data_ptr(), B, lv_n, npoint, radius, nsample,
+                                          idx.data_ptr(), st))
+                out = torch.empty((B, npoint, mlp[2]), dtype=f32, device=dev)
+                pk = self._packed["sa%d" % (li + 1)]
+                self._run("sa_group_mlp_pool[%d]" % (li + 1), lambda: lib.gn_sa_group_mlp_pool(lv_xyz.data_ptr(), L.ptr(lv_feat), new_xyz.data_ptr(), idx.data_ptr(),
+                                                 B, lv_n, npoint, nsample, c, radius, _ci(*mlp), pk.wptr, pk.bptr,
+                                                 out.data_ptr(), st))
+                name = "sa%d" % (li + 1)
+                if li < 2:
+                    end_points[name + "_inds"] = inds
+                end_points[name + "_xyz"] = new_xyz
+                end_points[name + "_features"] = out.transpose(1, 2)       # (B,C,np) view
+                lv_inds.append(inds)
+                feats.append(out)
+                lv_xyz, lv_feat, lv_n = new_xyz, out, npoint
+
+            # ---- 2 feature-propagation levels (backbone.py:124-125)
+            def fp(unknown_xyz, known_xyz, skip, known, key):
+                n, m = unknown_xyz.size(1), known_xyz.size(1)
+                d2 = torch.empty((B, n, 3), dtype=f32, device=dev)
+                i3 = torch.empty((B, n, 3), dtype=i32, device=dev)
+                self._run("three_nn[%s]" % key, lambda: lib.gn_three_nn(unknown_xyz.data_ptr(), known_xyz.data_ptr(), B, n, m, d2.data_ptr(),
+                                        i3.data_ptr(), st))
+                o = torch.empty((B, n, 256), dtype=f32, device=dev)
+                pk = self._packed[key]
+                self._run("fp_interp_mlp[%s]" % key, lambda: lib.gn_fp_interp_mlp(known.data_ptr(), skip.data_ptr(), d2.data_ptr(), i3.data_ptr(), B, n, m,
+                                             256, 256, _ci(256, 256), pk.wptr, pk.bptr, o.data_ptr(), st))
+                return o
+
+            g1 = fp(end_points["sa3_xyz"], end_points["sa4_xyz"], feats[2], feats[3], "fp1")
+            seed_feat = fp(end_points["sa2_xyz"], end_points["sa3_xyz"], feats[1], g1, "fp2")
+            seed_xyz = end_points["sa2_xyz"]
+            M = seed_xyz.size(1)
+            end_points["fp2_features"] = seed_feat.transpose(1, 2)
+            end_points["fp2_xyz"] = seed_xyz
+            end_points["fp2_inds"] = end_points["sa1_inds"][:, 0:M]             # backbone.py:129
+
+            # ---- ApproachNet (modules.py:41-77)
+            nv = 2 + self.num_view
+            feat302 = torch.empty((B, M, nv), dtype=f32, device=dev)
+            pk = self._packed["approach"]
+            self._run("approach_mlp", lambda: lib.gn_approach_mlp(seed_feat.data_ptr(), B * M, 256, nv, pk.wptr, pk.bptr, feat302.data_ptr(), st))
+            views, view_rot, decode_rot = self._tables
+            top_inds = torch.empty((B, M), dtype=torch.int64, device=dev)
+            top_score = torch.empty((B, M), dtype=f32, device=dev)
+            top_xyz = torch.empty((B, M, 3), dtype=f32, device=dev)
+            top_rot = torch.empty((B, M, 3, 3), dtype=f32, device=dev)
+            self._run("approach_post", lambda: lib.gn_approach_post(feat302.data_ptr(), nv, B * M, self.num_view, views.data_ptr(),
+                                         view_rot.data_ptr(), top_inds.data_ptr(), top_score.data_ptr(),
+                                         top_xyz.data_ptr(), top_rot.data_ptr(), st))
+            end_points["objectness_score"] = feat302[:, :, 0:2].transpose(1, 2)      # (B,2,M)
+            end_points["view_score"] = feat302[:, :, 2:]                             # (B,M,300)
+            end_points["grasp_top_view_inds"] = top_inds
+            end_points["grasp_top_view_score"] = top_score
+            end_points["grasp_top_view_xyz"] = top_xyz
+            end_points["grasp_top_view_rot"] = top_rot
+
+            # ---- CloudCrop (modules.py:109-141), inference branch of GraspNetStage2 (graspnet.py:53-57)
+            D, NS = self.num_depth, self.crop_nsample
+            cyl_idx = torch.empty((B, M, D, NS), dtype=i32, device=dev)
+            self._run("cylinder_query_multi", lambda: lib.gn_cylinder_query_multi(seed_xyz.data_ptr(), xyz.data_ptr(), top_rot.data_ptr(), B, N, M,
+                                                self.cylinder_radius, self.hmin, self.hmax, D, NS,
+                                                cyl_idx.data_ptr(), st))
+            vp = torch.empty((B, M * D, 256), dtype=f32, device=dev)
+            pk = self._packed["crop"]
+            self._run("crop_group_mlp_pool", lambda: lib.gn_crop_group_mlp_pool(xyz.data_ptr(), seed_xyz.data_ptr(), top_rot.data_ptr(),
+                                               cyl_idx.data_ptr(), B, N, M, D, NS, _ci(64, 128, 256), pk.wptr, pk.bptr,
+                                               vp.data_ptr(), st))
+
+            # ---- OperationNet + ToleranceNet (modules.py:169-191, 214-232)
+            A = self.num_angle
+            head = torch.empty((B, M, D, 4 * A), dtype=f32, device=dev)
+            pk = self._packed["heads"]
+            self._run("heads_mlp", lambda: lib.gn_heads_mlp(vp.data_ptr(), B * M * D, 256, 4 * A, pk.wptr, pk.bptr, head.data_ptr(), st))
+            hv = head.permute(0, 3, 1, 2)                                            # (B,48,M,D) view
+            end_points["grasp_score_pred"] = hv[:, 0:A]
+            end_points["grasp_angle_cls_pred"] = hv[:, A:2 * A]
+            end_points["grasp_width_pred"] = hv[:, 2 * A:3 * A]
+            end_points["grasp_tolerance_pred"] = hv[:, 3 * A:4 * A]
+            # private handles for the fused decode / tests
+            end_points["_gn"] = {"feat": feat302, "head": head, "model": self, "cyl_idx": cyl_idx, "vp": vp}
+        return end_points
+
+    @torch.no_grad()
+    def decode_padded(self, end_points):
+        """graspnet.py:77-134 for the whole batch, no host sync:
+        -> grasps (B,M,17) f32 padded with zero rows, counts (B,) i32."""
+        lib = L.lib()
+        priv = end_points.get("_gn")
+        if priv is not None:
+            feat, head = priv["feat"], priv["head"]
+        else:   # end_points produced elsewhere (e.g. the reference model on the drop-in operators)
+            feat = end_points["objectness_score"].transpose(1, 2).contiguous()      # (B,M,2)
+            head = torch.cat([end_points["grasp_score_pred"], end_points["grasp_angle_cls_pred"],
+                              end_points["grasp_width_pred"], end_points["grasp_tolerance_pred"]], dim=1)
+            head = head.permute(0, 2, 3, 1).contiguous()
+        top_inds = end_points["grasp_top_view_inds"].contiguous()
+        seed_xyz = end_points["fp2_xyz"].contiguous()
+        B, M = seed_xyz.size(0), seed_xyz.size(1)
+        dev = seed_xyz.device
+        grasps = torch.empty((B, M, GRASP_ROW), dtype=torch.float32, device=dev)
+        counts = torch.empty((B,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            self._run("pred_decode", lambda: lib.gn_pred_decode(feat.data_ptr(), feat.size(2), head.data_ptr(), top_inds.data_ptr(),
+                                       seed_xyz.data_ptr(), self._tables[2].data_ptr(), B, M, self.num_depth,
+                                       self.num_angle, grasps.data_ptr(), counts.data_ptr(), st))
+        return grasps, counts
+
+
+def _expected_keys():
+    from . import synthetic
+    return set(synthetic.make_state_dict(0, calibrated=False).keys())
+
+
+_DEFAULT_DECODER = None
+
+
+def pred_decode(end_points):
+    """Drop-in for models/graspnet.py:77 pred_decode: list of B tensors (Ns_i, 17)."""
+    global _DEFAULT_DECODER
+    priv = end_points.get("_gn")
+    if priv is not None:
+        model = priv["model"]
+    else:
+        if _DEFAULT_DECODER is None:
+            _DEFAULT_DECODER = GraspNet()
+            _DEFAULT_DECODER.device = end_points["fp2_xyz"].device
+            v, vr, dr = geometry.build_tables(300, 12)
+            _DEFAULT_DECODER._tables = (v.to(_DEFAULT_DECODER.device), vr.to(_DEFAULT_DECODER.device),
+                                        dr.to(_DEFAULT_DECODER.device))
+        model = _DEFAULT_DECODER
+    grasps, counts = model.decode_padded(end_points)
+    cnt = counts.cpu().tolist()          # the only host sync; the reference's callers sync here too (test.py:88)
+    return [grasps[i, :c] for i, c in enumerate(cnt)]

@@ -1,0 +1,107 @@
+"""Host-side weight preparation: fold eval-mode BatchNorm into the 1x1 convs and pack the result in
+the MFMA fragment order the kernels read (csrc/mlp_core.h).
+
+Input is a state-dict with the reference's key layout (models/graspnet.py:63-68 and children; see
+tests/golden/state_dict_manifest.txt), e.g. what `torch.load(ckpt)['model_state_dict']` holds.
+"""
+import torch
+
+BN_EPS = 1e-5   # torch.nn.BatchNorm1d/2d default used by pytorch_utils.py:40-60, modules.py:38-39
+
+
+def fold_bn(w, b, sd, bn):
+    """conv (Cout,Cin[,1[,1]]) [+bias] followed by BN(eval) -> (W', b') in float64 -> float32."""
+    w = w.reshape(w.shape[0], -1).double()
+    cout = w.shape[0]
+    b = torch.zeros(cout, dtype=torch.float64) if b is None else b.double()
+    if bn is not None:
+        scale = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + BN_EPS)
+        w = w * scale[:, None]
+        b = (b - sd[bn + ".running_mean"].double()) * scale + sd[bn + ".bias"].double()
+    return w.float(), b.float()
+
+
+def pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+def coutp_for(cout):
+    """COUT padded so its 32-wide tiles divide over the 4 waves (csrc/mlp_core.h wn_for)."""
+    p = pad_to(cout, 32)
+    return pad_to(p, 128) if p // 32 >= 4 else p
+
+
+def pack_fragments(w, b, cinp=None, coutp=None):
+    """(Cout,Cin) f32, (Cout,) -> Wp[nt][kb][lane][s] = W[nt*32+(lane&31)][kb*8+4*(lane>>5)+s], padded bias."""
+    cout, cin = w.shape
+    cinp = pad_to(cin, 8) if cinp is None else cinp
+    coutp = coutp_for(cout) if coutp is None else coutp
+    wp = torch.zeros(coutp, cinp, dtype=torch.float32)
+    wp[:cout, :cin] = w
+    bp = torch.zeros(coutp, dtype=torch.float32)
+    bp[:cout] = b
+    nt, kb = coutp // 32, cinp // 8
+    frag = wp.reshape(nt, 32, kb, 2, 4).permute(0, 2, 3, 1, 4).contiguous().reshape(nt, kb, 64, 4)
+    return frag.contiguous(), bp
+
+
+class PackedMlp:
+    """Device-resident packed layers + the ctypes pointer arrays the C ABI takes."""
+
+    def __init__(self, layers, device):
+        import ctypes
+        self.w = [w.to(device) for w, _ in layers]
+        self.b = [b.to(device) for _, b in layers]
+        n = len(layers)
+        self.wptr = (ctypes.c_void_p * n)(*[t.data_ptr() for t in self.w])
+        self.bptr = (ctypes.c_void_p * n)(*[t.data_ptr() for t in self.b])
+
+
+def _shared_mlp_layers(sd, prefix, nlayers):
+    return [fold_bn(sd["%s.layer%d.conv.weight" % (prefix, i)], None, sd, "%s.layer%d.bn.bn" % (prefix, i))
+            for i in range(nlayers)]
+
+
+def prepare(sd, device, num_view=300, num_angle=12):
+    """-> dict of PackedMlp for every stage."""
+    sd = {k: v.detach().cpu() for k, v in sd.items()}
+    out = {}
+    bb = "view_estimator.backbone"
+    for li in range(4):
+        layers = _shared_mlp_layers(sd, "%s.sa%d.mlp_module" % (bb, li + 1), 3)
+        w0, b0 = layers[0]
+        c = w0.shape[1] - 3
+        # reference input order is [xyz(3) | features(C)] (pointnet2_utils.py:353); kernels use [features | xyz | pad]
+        w0 = torch.cat([w0[:, 3:], w0[:, :3]], dim=1)
+        packed = [pack_fragments(w0, b0, cinp=c + 8)] + [pack_fragments(w, b) for w, b in layers[1:]]
+        out["sa%d" % (li + 1)] = PackedMlp(packed, device)
+    for i in (1, 2):
+        layers = _shared_mlp_layers(sd, "%s.fp%d.mlp" % (bb, i), 2)
+        out["fp%d" % i] = PackedMlp([pack_fragments(w, b) for w, b in layers], device)
+    vp = "view_estimator.vpmodule"
+    nv = 2 + num_view
+    l1 = fold_bn(sd[vp + ".conv1.weight"], sd[vp + ".conv1.bias"], sd, vp + ".bn1")
+    l2 = fold_bn(sd[vp + ".conv2.weight"], sd[vp + ".conv2.bias"], sd, vp + ".bn2")
+    l3 = fold_bn(sd[vp + ".conv3.weight"], sd[vp + ".conv3.bias"], sd, None)
+    nvp = coutp_for(nv)
+    out["approach"] = PackedMlp([pack_fragments(*l1), pack_fragments(*l2, coutp=nvp),
+                                 pack_fragments(*l3, cinp=pad_to(nv, 8), coutp=nvp)], device)
+    out["crop"] = PackedMlp([pack_fragments(w, b, cinp=8 if i == 0 else None)
+                             for i, (w, b) in enumerate(_shared_mlp_layers(sd, "grasp_generator.crop.mlps", 3))], device)
+    # OperationNet + ToleranceNet as one chain: conv1 stacked, conv2 / conv3 block-diagonal
+    op, tl = "grasp_generator.operation", "grasp_generator.tolerance"
+    o1 = fold_bn(sd[op + ".conv1.weight"], sd[op + ".conv1.bias"], sd, op + ".bn1")
+    t1 = fold_bn(sd[tl + ".conv1.weight"], sd[tl + ".conv1.bias"], sd, tl + ".bn1")
+    o2 = fold_bn(sd[op + ".conv2.weight"], sd[op + ".conv2.bias"], sd, op + ".bn2")
+    t2 = fold_bn(sd[tl + ".conv2.weight"], sd[tl + ".conv2.bias"], sd, tl + ".bn2")
+    o3 = fold_bn(sd[op + ".conv3.weight"], sd[op + ".conv3.bias"], sd, None)
+    t3 = fold_bn(sd[tl + ".conv3.weight"], sd[tl + ".conv3.bias"], sd, None)
+    h = o1[0].shape[0]                       # 128
+    w1 = torch.cat([o1[0], t1[0]], 0); b1 = torch.cat([o1[1], t1[1]], 0)
+    w2 = torch.zeros(2 * h, 2 * h); w2[:h, :h] = o2[0]; w2[h:, h:] = t2[0]
+    b2 = torch.cat([o2[1], t2[1]], 0)
+    no, nt_ = o3[0].shape[0], t3[0].shape[0]   # 36, 12
+    w3 = torch.zeros(no + nt_, 2 * h); w3[:no, :h] = o3[0]; w3[no:, h:] = t3[0]
+    b3 = torch.cat([o3[1], t3[1]], 0)
+    out["heads"] = PackedMlp([pack_fragments(w1, b1), pack_fragments(w2, b2), pack_fragments(w3, b3)], device)
+    return out

@@ -112,6 +112,74 @@ int gn_three_interpolate_grad(const float *grad_out, const int32_t *idx, const f
 int gn_knn(const float *ref, const float *query, int b, int d, int nr, int nq, int k, int64_t *idx,
            float *scratch, gn_stream_t stream);
 
+/* ------------------------------------------------------------------ *
+ *  Fused stages behind models/graspnet.py GraspNet.forward / pred_decode
+ *  Activations between stages are POSITION-major ("channels last"):
+ *  features (B, npoint, C).  Weights are BN-folded on the host and packed
+ *  in MFMA fragment order (graspnet_amd/weights.py: pack_fragments):
+ *    Wp[nt][kb][lane][s] = W[nt*32 + (lane&31)][kb*8 + 4*(lane>>5) + s]
+ *  with COUT padded to a multiple of 32 (x4 waves where it has >= 4 tiles)
+ *  and CIN to a multiple of 8; bias padded to the same COUT.
+ * ------------------------------------------------------------------ */
+
+/* CloudCrop's four CylinderQueryAndGroup queries (models/modules.py:103-106,127-130) in one scan:
+ * idx (B, M, ndepth, nsample) i32, each depth with the exact semantics of gn_cylinder_query.
+ * hmax_host: HOST array of ndepth floats.  ndepth must be 4. */
+int gn_cylinder_query_multi(const float *new_xyz, const float *xyz, const float *rot, int b, int n, int m,
+                            float radius, float hmin, const float *hmax_host, int ndepth, int nsample,
+                            int32_t *idx, gn_stream_t stream);
+
+/* Set-abstraction tail: group by idx, subtract centre, divide by radius, concat features,
+ * SharedMLP(3 layers, BN folded, ReLU), max-pool over nsample
+ * (pointnet2_utils.py:344-355 + pointnet2_modules.py:251-257).
+ * xyz (B,N,3); feat (B,N,C) channels-last or NULL when C=0; new_xyz (B,NP,3); idx (B,NP,NS);
+ * mlp = {c1,c2,c3}; wpacked/bias: HOST arrays of 3 device pointers; the first layer's input
+ * columns are ordered [features(C) | xyz(3) | zero pad]; out (B,NP,c3) channels-last.
+ * Supported: (C,mlp,NS) of models/backbone.py:30-64. */
+int gn_sa_group_mlp_pool(const float *xyz, const float *feat, const float *new_xyz, const int32_t *idx,
+                         int b, int n, int np, int ns, int c, float radius, const int *mlp,
+                         const float *const *wpacked, const float *const *bias, float *out,
+                         gn_stream_t stream);
+
+/* CloudCrop tail: group xyz by idx (B,M,ndepth,NS), subtract seed, rotate into the view frame,
+ * SharedMLP[3,64,128,256], max-pool (pointnet2_utils.py:521-530 + models/modules.py:131-140).
+ * out (B, M*ndepth, 256) channels-last, group order [seed][depth]. */
+int gn_crop_group_mlp_pool(const float *xyz, const float *seed_xyz, const float *rot, const int32_t *idx,
+                           int b, int n, int m, int ndepth, int ns, const int *mlp,
+                           const float *const *wpacked, const float *const *bias, float *out,
+                           gn_stream_t stream);
+
+/* PointnetFPModule tail (pointnet2_modules.py:395-416): inverse-distance weights from three_nn's
+ * dist2/idx, three_interpolate, concat skip features, SharedMLP(2 layers).
+ * known_feat (B,m,ck), skip_feat (B,n,cs) channels-last -> out (B,n,mlp[1]). */
+int gn_fp_interp_mlp(const float *known_feat, const float *skip_feat, const float *dist2,
+                     const int32_t *idx3, int b, int n, int m, int ck, int cs, const int *mlp,
+                     const float *const *wpacked, const float *const *bias, float *out,
+                     gn_stream_t stream);
+
+/* ApproachNet conv1/bn1/relu, conv2/bn2/relu, conv3 (models/modules.py:55-57):
+ * x (rows,256) -> out (rows, 2+num_view) = [objectness | view scores]. */
+int gn_approach_mlp(const float *x, int rows, int cin, int nout, const float *const *wpacked,
+                    const float *const *bias, float *out, gn_stream_t stream);
+
+/* OperationNet + ToleranceNet conv chains (models/modules.py:171-175, 216-220) as one
+ * 256->256->256->48 chain: out (rows,48) = [score(12) | angle cls(12) | width(12) | tolerance(12)]. */
+int gn_heads_mlp(const float *x, int rows, int cin, int nout, const float *const *wpacked,
+                 const float *const *bias, float *out, gn_stream_t stream);
+
+/* models/modules.py:64-76: top view = first arg-max over view scores; template / rotation lookup.
+ * feat (rows, ldf) = [objectness(2) | nview scores]; views (nview,3); view_rot (nview,9). */
+int gn_approach_post(const float *feat, int ldf, int rows, int nview, const float *views,
+                     const float *view_rot, int64_t *top_inds, float *top_score, float *top_xyz,
+                     float *top_rot, gn_stream_t stream);
+
+/* models/graspnet.py:77-134 pred_decode for a whole batch: grasps (B,M,17) padded rows
+ * [score,width,height,depth,R(9),center(3),obj_id], counts (B) valid rows per scene (rows keep seed
+ * order; rows >= count are zero).  head (B,M,ndepth,4*nangle); rot_table (nview*nangle*9). */
+int gn_pred_decode(const float *feat, int ldf, const float *head, const int64_t *top_inds,
+                   const float *seed_xyz, const float *rot_table, int b, int m, int ndepth, int nangle,
+                   float *grasps, int32_t *counts, gn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

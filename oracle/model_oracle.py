@@ -66,16 +66,25 @@ def shared_mlp(x, sd, prefix, nlayers):
     return x
 
 
-def sa_module(xyz, features, sd, prefix, npoint, radius, nsample):
+def _group(features, idx):
+    """group_points for any dtype (float64 'truth' mode uses torch indexing; a pure copy either way)."""
+    if features.dtype == torch.float32:
+        return ops.group_points(features.contiguous(), idx)
+    b, c, n = features.shape
+    ix = idx.long().reshape(b, 1, -1).expand(-1, c, -1)
+    return torch.gather(features, 2, ix).reshape(b, c, idx.shape[1], idx.shape[2])
+
+
+def sa_module(xyz, features, sd, prefix, npoint, radius, nsample, dt=torch.float32):
     xyz_flipped = xyz.transpose(1, 2).contiguous()
     inds = ops.furthest_point_sampling(xyz, npoint)
     new_xyz = ops.gather_points(xyz_flipped, inds).transpose(1, 2).contiguous()
     idx = ops.ball_query(new_xyz, xyz, radius, nsample)
-    grouped_xyz = ops.group_points(xyz_flipped, idx)
-    grouped_xyz -= new_xyz.transpose(1, 2).unsqueeze(-1)
+    grouped_xyz = ops.group_points(xyz_flipped, idx).to(dt)
+    grouped_xyz -= new_xyz.to(dt).transpose(1, 2).unsqueeze(-1)
     grouped_xyz /= radius                      # normalize_xyz=True, backbone.py:36
     if features is not None:
-        grouped = torch.cat([grouped_xyz, ops.group_points(features, idx)], dim=1)
+        grouped = torch.cat([grouped_xyz, _group(features, idx)], dim=1)
     else:
         grouped = grouped_xyz
     new_features = shared_mlp(grouped, sd, prefix + ".mlp_module", 3)
@@ -85,23 +94,29 @@ def sa_module(xyz, features, sd, prefix, npoint, radius, nsample):
 
 def fp_module(unknown, known, unknow_feats, known_feats, sd, prefix):
     dist2, idx = ops.three_nn(unknown, known)
-    dist = torch.sqrt(dist2)                   # pointnet2_utils.py:138-140
+    dt = known_feats.dtype
+    dist = torch.sqrt(dist2.to(dt))            # pointnet2_utils.py:138-140
     dist_recip = 1.0 / (dist + 1e-8)
     norm = torch.sum(dist_recip, dim=2, keepdim=True)
     weight = dist_recip / norm
-    interpolated = ops.three_interpolate(known_feats, idx, weight.contiguous())
+    if dt == torch.float32:
+        interpolated = ops.three_interpolate(known_feats.contiguous(), idx, weight.contiguous())
+    else:
+        b, c, m = known_feats.shape
+        interpolated = sum(torch.gather(known_feats, 2, idx[:, :, i].long().unsqueeze(1).expand(-1, c, -1))
+                           * weight[:, :, i].unsqueeze(1) for i in range(3))
     new_features = torch.cat([interpolated, unknow_feats], dim=1).unsqueeze(-1)
     return shared_mlp(new_features, sd, prefix + ".mlp", 2).squeeze(-1)
 
 
-def backbone(pointcloud, sd, end_points):
+def backbone(pointcloud, sd, end_points, dt=torch.float32):
     p = "view_estimator.backbone"
     xyz = pointcloud[..., 0:3].contiguous()
     end_points["input_xyz"] = xyz
     end_points["input_features"] = None
     features = None
     for li, (npoint, radius, nsample) in enumerate(SA_CFG):
-        xyz, features, inds = sa_module(xyz, features, sd, "%s.sa%d" % (p, li + 1), npoint, radius, nsample)
+        xyz, features, inds = sa_module(xyz, features, sd, "%s.sa%d" % (p, li + 1), npoint, radius, nsample, dt)
         if li < 2:
             end_points["sa%d_inds" % (li + 1)] = inds
         end_points["sa%d_xyz" % (li + 1)] = xyz
@@ -145,7 +160,7 @@ def viewpoint_to_matrix(towards, angle):
     return torch.matmul(r2, r1)
 
 
-def approach_net(seed_xyz, seed_features, sd, end_points, num_view=300):
+def approach_net(seed_xyz, seed_features, sd, end_points, num_view=300, force_top_view_inds=None):
     p = "view_estimator.vpmodule"
     B, num_seed, _ = seed_xyz.size()
     f = F.relu(_bn(F.conv1d(seed_features, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"]), sd, p + ".bn1"))
@@ -155,6 +170,9 @@ def approach_net(seed_xyz, seed_features, sd, end_points, num_view=300):
     view_score = f[:, 2:2 + num_view, :].transpose(1, 2).contiguous()
     end_points["view_score"] = view_score
     top_view_scores, top_view_inds = torch.max(view_score, dim=2)
+    if force_top_view_inds is not None:        # float64 'truth' mode follows the fp32 oracle's discrete choice
+        top_view_inds = force_top_view_inds
+        top_view_scores = torch.gather(view_score, 2, top_view_inds.unsqueeze(-1)).squeeze(-1)
     template = grasp_views(num_view)
     vp_xyz = template[top_view_inds.reshape(-1)].view(B, num_seed, 3)
     vp_rot = viewpoint_to_matrix(-vp_xyz.view(-1, 3), torch.zeros(B * num_seed)).view(B, num_seed, 3, 3)
@@ -166,7 +184,7 @@ def approach_net(seed_xyz, seed_features, sd, end_points, num_view=300):
 
 
 def cloud_crop(seed_xyz, pointcloud, vp_rot, sd, nsample=64, radius=0.05, hmin=-0.02,
-               hmax_list=(0.01, 0.02, 0.03, 0.04), return_idx=False):
+               hmax_list=(0.01, 0.02, 0.03, 0.04), return_idx=False, dt=torch.float32):
     B, num_seed, _, _ = vp_rot.size()
     xyz_trans = pointcloud.transpose(1, 2).contiguous()
     grouped, idxs = [], []
@@ -174,10 +192,10 @@ def cloud_crop(seed_xyz, pointcloud, vp_rot, sd, nsample=64, radius=0.05, hmin=-
         idx = ops.cylinder_query(seed_xyz, pointcloud, vp_rot.reshape(B, num_seed, 9).contiguous(),
                                  radius, hmin, hmax, nsample)
         idxs.append(idx)
-        g = ops.group_points(xyz_trans, idx)
-        g -= seed_xyz.transpose(1, 2).unsqueeze(-1)
+        g = ops.group_points(xyz_trans, idx).to(dt)
+        g -= seed_xyz.to(dt).transpose(1, 2).unsqueeze(-1)
         g_ = g.permute(0, 2, 3, 1).contiguous()
-        g_ = torch.matmul(g_, vp_rot)
+        g_ = torch.matmul(g_, vp_rot.to(dt))
         grouped.append(g_.permute(0, 3, 1, 2).contiguous())
     x = torch.stack(grouped, dim=3).view(B, -1, num_seed * len(hmax_list), nsample)
     x = shared_mlp(x, sd, "grasp_generator.crop.mlps", 3)
@@ -197,14 +215,21 @@ def head_net(vp_features, sd, p):
     return x.view(B, -1, num_seed, num_depth)
 
 
-def forward(end_points, sd, num_view=300, num_angle=12, keep_internal=False):
-    """GraspNet.forward, is_training=False (graspnet.py:70-75)."""
+def forward(end_points, sd, num_view=300, num_angle=12, keep_internal=False, f64=False, force_top_view_inds=None):
+    """GraspNet.forward, is_training=False (graspnet.py:70-75).
+
+    f64=True evaluates every conv / BN / interpolation in float64 on the SAME neighbour indices
+    (index operators still see the float32 coordinates): the "exact arithmetic" yardstick that the
+    parity tests measure both the fp32 oracle and the HIP path against."""
     with torch.no_grad():
         pc = end_points["point_clouds"]
-        seed_features, seed_xyz, end_points = backbone(pc, sd, end_points)
-        end_points = approach_net(seed_xyz, seed_features, sd, end_points, num_view)
+        dt = torch.float64 if f64 else torch.float32
+        if f64:
+            sd = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        seed_features, seed_xyz, end_points = backbone(pc, sd, end_points, dt)
+        end_points = approach_net(seed_xyz, seed_features, sd, end_points, num_view, force_top_view_inds)
         vp, cyl_idx = cloud_crop(end_points["fp2_xyz"], end_points["input_xyz"],
-                                 end_points["grasp_top_view_rot"], sd, return_idx=True)
+                                 end_points["grasp_top_view_rot"], sd, return_idx=True, dt=dt)
         if keep_internal:
             end_points["_vp_features"] = vp
             end_points["_cylinder_idx"] = cyl_idx

@@ -1,0 +1,68 @@
+"""CPU (gloo, world_size 2): scene sharding and the all-gather of padded grasp lists."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "graspnet-baseline_amd"))
+    from graspnet_amd import dist as gdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B_global, M = 6, 16
+        lo, hi = gdist.shard_range(B_global, rank, world)
+        g = torch.zeros(hi - lo, M, 17)
+        c = torch.zeros(hi - lo, dtype=torch.int32)
+        for i, scene in enumerate(range(lo, hi)):      # scene s holds s+1 grasps whose score is s
+            c[i] = scene + 1
+            g[i, :scene + 1, 0] = float(scene)
+        ga, ca = gdist.all_gather_grasps(g, c)
+        lst = gdist.to_list(ga, ca)
+        ok = (ga.shape == (B_global, M, 17) and ca.tolist() == [s + 1 for s in range(B_global)]
+              and all(t.shape == (s + 1, 17) and bool((t[:, 0] == s).all()) for s, t in enumerate(lst)))
+        q.put((rank, ok, (lo, hi)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_ranges_partition_the_batch():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "graspnet-baseline_amd"))
+    from graspnet_amd.dist import shard_range
+    for gb in (1, 7, 8, 64, 65):
+        for w in (1, 2, 3, 8):
+            r = [shard_range(gb, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == gb
+            assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
+
+
+def test_all_gather_grasps_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert sorted(r for _, _, r in res) == [(0, 3), (3, 6)]

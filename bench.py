@@ -38,7 +38,8 @@ def cpu_baseline(n_scenes, n_points):
     from oracle import model_oracle as MO, oracle as O
     from graspnet_amd import synthetic as S
     O.build()
-    cores = os.cpu_count() or 1
+    # a one-GPU box's CPU share is 16 cores; hundreds of torch/OpenMP threads on these small convs thrash
+    cores = min(os.cpu_count() or 1, 16)
     O.set_num_threads(cores)
     torch.set_num_threads(cores)
     sd = S.make_state_dict(0)
@@ -59,8 +60,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="scenes per GPU per step")
     ap.add_argument("--points", type=int, default=20000)
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams the steps are issued round-robin on (FPS is a serial chain on 8 CUs per "
+                         "batch; other batches' kernels fill the rest of the chip meanwhile)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-scenes", type=int, default=4)
+    ap.add_argument("--cpu-scenes", type=int, default=3)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -83,22 +87,26 @@ def main():
     lo, _ = gdist.shard_range(world * B, rank, world)
     clouds = S.make_batch(1000 + lo, B, N, "uniform").to(dev)
 
-    def step():
-        ep = net({"point_clouds": clouds})
-        g, c = net.decode_padded(ep)
-        if world > 1:
-            g, c = gdist.all_gather_grasps(g, c)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+    torch.cuda.synchronize()
+
+    def step(i):
+        with torch.cuda.stream(streams[i % len(streams)]):
+            ep = net({"point_clouds": clouds})
+            g, c = net.decode_padded(ep)
+            if world > 1:
+                g, c = gdist.all_gather_grasps(g, c)
         return g, c
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     net.timing = {}          # HIP-event brackets around every kernel launch, recorded in the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        g, c = step()
+    for i in range(args.steps):
+        g, c = step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -132,7 +140,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "config[1]: batch %d x %d-pt synthetic clouds per GPU, full SA->ApproachNet->"
                                    "CloudCrop->OperationNet/ToleranceNet->pred_decode, seeded random weights" % (B, N),
-                       "batch_per_gpu": B, "points": N, "parallelism": "scene shards x%d" % world},
+                       "batch_per_gpu": B, "points": N, "parallelism": "scene shards x%d" % world,
+                       "streams": len(streams)},
             "roofline": roof,
             "dominant_kernel": dom, "dominant_kernel_roofline_key": key,
             "kernel_ms": {k: round(v, 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])},

@@ -31,9 +31,18 @@ __device__ __forceinline__ int bitrev_bits(int v, int bits) {
   return bits ? (int)(__brev((unsigned)v) >> (32 - bits)) : 0;
 }
 
-// position in rank order -> original point index, or -1 for padding
-__device__ __forceinline__ int pos_to_k(int p, int bs, int lg, int Q, int n) {
-  const int r = p / Q;
+// v_min_f32 without the canonicalising v_max pair hipcc wraps around fminf(): IEEE min, returns
+// the non-NaN operand like CUDA's min(float,float) (sampling_gpu.cu:111).
+__device__ __forceinline__ float vmin(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// position in rank order -> original point index, or -1 for padding.
+// qmagic = ceil(2^32 / Q): floor(p / Q) == umulhi(p, qmagic) for p < 2^15 <= 2^32 / Q (host checks).
+__device__ __forceinline__ int pos_to_k(int p, int bs, int lg, int Q, unsigned qmagic, int n) {
+  const int r = Q == 1 ? p : (int)__umulhi((unsigned)p, qmagic);
   const int q = p - r * Q;
   if (r >= bs) return -1;
   const int k = q * bs + bitrev_bits(r, lg);
@@ -42,7 +51,7 @@ __device__ __forceinline__ int pos_to_k(int p, int bs, int lg, int Q, int n) {
 
 template <int NT, int PPT>
 __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ xyz, int n, int m,
-                                                      int bs, int lg, int Q,
+                                                      int bs, int lg, int Q, unsigned qmagic,
                                                       int32_t *__restrict__ idx,
                                                       float *__restrict__ new_xyz) {
   constexpr int NW = NT / 64;
@@ -60,7 +69,7 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
   float px[PPT], py[PPT], pz[PPT], tmp[PPT];
 #pragma unroll
   for (int s = 0; s < PPT; ++s) {
-    const int k = pos_to_k(t * PPT + s, bs, lg, Q, n);
+    const int k = pos_to_k(t * PPT + s, bs, lg, Q, qmagic, n);
     float x = 0.f, y = 0.f, z = 0.f, t0 = -1.0f;
     if (k >= 0) {
       x = xyz[k * 3 + 0];
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
     for (int s = 0; s < PPT; ++s) {
       const float dx = px[s] - x1, dy = py[s] - y1, dz = pz[s] - z1;
       const float d = dx * dx + dy * dy + dz * dz;
-      const float d2 = __builtin_fminf(d, tmp[s]);
+      const float d2 = vmin(d, tmp[s]);
       tmp[s] = d2;
       const bool gt = d2 > best;
       best = gt ? d2 : best;
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
     const int w = eq2 ? (__ffsll((long long)eq2) - 1) : 0;
     const int gpos = __builtin_amdgcn_readlane(pp, w);
     // all candidates skipped -> best=-1,besti=0 in every reference thread -> index 0
-    int k = gmax >= 0.0f ? pos_to_k(gpos, bs, lg, Q, n) : 0;
+    int k = gmax >= 0.0f ? pos_to_k(gpos, bs, lg, Q, qmagic, n) : 0;
     k = __builtin_amdgcn_readfirstlane(k < 0 ? 0 : k);
     x1 = xyz[k * 3 + 0];
     y1 = xyz[k * 3 + 1];
@@ -225,10 +234,12 @@ extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m,
   while ((1 << lg) < bs) ++lg;
   const int Q = (n + bs - 1) / bs;
   const long need = (long)bs * Q;
+  // ceil(2^32 / Q); exact floor-division for every position < 2^15 (register kernels hold <= 24576)
+  const unsigned qmagic = Q == 1 ? 0xffffffffu : (unsigned)((0x100000000ull + Q - 1) / Q);
   hipStream_t s = as_stream(stream);
 #define GN_FPS_LAUNCH(NT, PPT)                                                                    \
-  hipLaunchKernelGGL((fps_reg_kernel<NT, PPT>), dim3(b), dim3(NT), 0, s, xyz, n, m, bs, lg, Q, idx, \
-                     new_xyz)
+  hipLaunchKernelGGL((fps_reg_kernel<NT, PPT>), dim3(b), dim3(NT), 0, s, xyz, n, m, bs, lg, Q, qmagic, \
+                     idx, new_xyz)
   if (need <= 256 * 2) GN_FPS_LAUNCH(256, 2);
   else if (need <= 256 * 4) GN_FPS_LAUNCH(256, 4);
   else if (need <= 1024 * 2) GN_FPS_LAUNCH(1024, 2);

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(MLP_THREADS) void sa_mlp_kernel(const float *__rest
                                                              const float *__restrict__ feat,
                                                              const float *__restrict__ new_xyz,
                                                              const int32_t *__restrict__ idx, int np, int ntiles,
-                                                             float radius, Mlp3Weights W, float *__restrict__ out) {
+                                                             int tpb, float radius, Mlp3Weights W,
+                                                             float *__restrict__ out) {
   constexpr int CIN0 = C + 8;
   constexpr int GPT = TP / NS;  // groups per tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -73,7 +74,10 @@ __global__ __launch_bounds__(MLP_THREADS) void sa_mlp_kernel(const float *__rest
   w2.load(W.w2, W.b2, wave, lane);
   w3.load(W.w3, W.b3, wave, lane);
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // a block owns `tpb` consecutive tiles (weights loaded once per block); the grid is larger than the
+  // chip so the hardware dispatcher balances blocks over whatever CUs other streams leave free
+  const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * tpb);
+  for (int tile = blockIdx.x * tpb; tile < tile_end; ++tile) {
     const int g0 = tile * GPT;   // first (flat) group of the tile; np % GPT == 0 so it stays in one cloud
     const int b = g0 / np;
     load_sa_tile<C, TP, NS>(bufA, xyz + (size_t)b * n * 3, C > 0 ? feat + (size_t)b * n * C : nullptr,
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_mlp_kernel(const float *__re
                                                                const float *__restrict__ seed,
                                                                const float *__restrict__ rot,
                                                                const int32_t *__restrict__ idx, int m, int ntiles,
-                                                               Mlp3Weights W, float *__restrict__ out) {
+                                                               int tpb, Mlp3Weights W, float *__restrict__ out) {
   constexpr int CIN0 = 8;
   constexpr int GPT = TP / NS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -113,7 +117,8 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_mlp_kernel(const float *__re
   w3.load(W.w3, W.b3, wave, lane);
 
   const int gpc = m * ND;  // groups per cloud
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * tpb);
+  for (int tile = blockIdx.x * tpb; tile < tile_end; ++tile) {
     const int g0 = tile * GPT;
     const int b = g0 / gpc;
     const int gl = g0 - b * gpc;  // first group within the cloud
@@ -155,7 +160,9 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_mlp_kernel(const float *__re
   }
 }
 
-static int persistent_grid(int ntiles) {
+// tiles per block: amortise the per-block weight load over up to 8 tiles while keeping >= ~4 blocks
+// per CU in the grid (dynamic balance, and room for concurrent streams)
+static int tiles_per_block(int ntiles) {
   static int cus = 0;
   if (!cus) {
     int dev = 0;
@@ -163,7 +170,8 @@ static int persistent_grid(int ntiles) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
     if (cus <= 0) cus = 256;
   }
-  return ntiles < cus ? ntiles : cus;
+  int t = ntiles / (4 * cus);
+  return t < 1 ? 1 : (t > 8 ? 8 : t);
 }
 
 template <class K>
@@ -185,8 +193,9 @@ static int launch_sa(const float *xyz, const float *feat, const float *new_xyz, 
   auto k = sa_mlp_kernel<C, C1, C2, C3, NS, TP>;
   int rc = set_lds(k, lds, "sa_group_mlp_pool");
   if (rc) return rc;
-  hipLaunchKernelGGL(k, dim3(persistent_grid(ntiles)), dim3(MLP_THREADS), lds, s, xyz, n, feat, new_xyz, idx, np,
-                     ntiles, radius, W, out);
+  const int tpb = tiles_per_block(ntiles);
+  hipLaunchKernelGGL(k, dim3((ntiles + tpb - 1) / tpb), dim3(MLP_THREADS), lds, s, xyz, n, feat, new_xyz, idx, np,
+                     ntiles, tpb, radius, W, out);
   GN_CHECK_LAUNCH("sa_group_mlp_pool");
   return GN_OK;
 }
@@ -239,8 +248,9 @@ extern "C" int gn_crop_group_mlp_pool(const float *xyz, const float *seed_xyz, c
   auto k = crop_mlp_kernel<64, 128, 256, NS, ND, TP>;
   int rc = set_lds(k, lds, "crop_group_mlp_pool");
   if (rc) return rc;
-  hipLaunchKernelGGL(k, dim3(persistent_grid(ntiles)), dim3(MLP_THREADS), lds, as_stream(stream), xyz, n, seed_xyz,
-                     rot, idx, m, ntiles, W, out);
+  const int tpb = tiles_per_block(ntiles);
+  hipLaunchKernelGGL(k, dim3((ntiles + tpb - 1) / tpb), dim3(MLP_THREADS), lds, as_stream(stream), xyz, n, seed_xyz,
+                     rot, idx, m, ntiles, tpb, W, out);
   GN_CHECK_LAUNCH("crop_group_mlp_pool");
   return GN_OK;
 }

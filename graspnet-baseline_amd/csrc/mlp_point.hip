@@ -112,17 +112,6 @@ __global__ __launch_bounds__(MLP_THREADS) void point_mlp_kernel(PointMlpArgs a, 
   }
 }
 
-int persistent_grid_pm(int ntiles) {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
-  return ntiles < cus ? ntiles : cus;
-}
-
 template <int LOADER, int C0P, int C1P, int C1L, int C2P, int C2L, int C3P, int KC1, int KC2, int KC3, int TP,
           bool RELU_OUT>
 static int launch_point_mlp(const PointMlpArgs &a, hipStream_t s, const char *name) {
@@ -136,7 +125,7 @@ static int launch_point_mlp(const PointMlpArgs &a, hipStream_t s, const char *na
     return GN_ERR_LAUNCH;
   }
   const int ntiles = (a.nrows + TP - 1) / TP;
-  hipLaunchKernelGGL(k, dim3(persistent_grid_pm(ntiles)), dim3(MLP_THREADS), lds, s, a, ntiles);
+  hipLaunchKernelGGL(k, dim3(ntiles), dim3(MLP_THREADS), lds, s, a, ntiles);   // weights stream per tile anyway
   GN_CHECK_LAUNCH(name);
   return GN_OK;
 }

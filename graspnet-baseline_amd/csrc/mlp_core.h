@@ -174,14 +174,27 @@ __device__ __forceinline__ void run_layer(const LayerW<CINP, COUTP> &w, const fl
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = w.bias[i];
     const float *xr = xs + (mt * 32 + (lane & 31)) * XS + 4 * (lane >> 5);
+    // All A fragments are read in program order, then consumed; the sched_group_barrier ladder
+    // below pins the emitted order to [2 reads] ([4*NTW MFMAs][1 read])* so every ds_read_b128 is in
+    // flight two k-blocks ahead of its MFMAs (hipcc otherwise reads right before use and waits).
+    f32x4 a[LW::KB];
 #pragma unroll
-    for (int kb = 0; kb < LW::KB; ++kb) {
-      const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + kb * 8);
+    for (int kb = 0; kb < LW::KB; ++kb) a[kb] = *reinterpret_cast<const f32x4 *>(xr + kb * 8);
+#pragma unroll
+    for (int kb = 0; kb < LW::KB; ++kb)
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < LW::NTW; ++i)
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w.b[i][kb][s], acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kb][s], w.b[i][kb][s], acc[i], 0, 0, 0);
+    if constexpr (LW::KB > 2) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                 // DS read x2
+#pragma unroll
+      for (int kb = 0; kb < LW::KB - 2; ++kb) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * LW::NTW, 0);     // MFMAs of k-block kb
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               // read k-block kb+2
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 8 * LW::NTW, 0);
     }
 #pragma unroll
     for (int i = 0; i < LW::NTW; ++i) epi(mt, wn * LW::NTW + i, i, acc[i]);
@@ -225,14 +238,24 @@ __device__ __forceinline__ void run_layer_stream(const float *__restrict__ wp, c
     for (int mi = 0; mi < MTW; ++mi) {
       const int mt = wm * MTW + mi;
       const float *xr = xs + (mt * 32 + (lane & 31)) * XS + 4 * (lane >> 5) + kc * 8;
+      f32x4 a[KBC];
 #pragma unroll
-      for (int kb = 0; kb < KBC; ++kb) {
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + kb * 8);
+      for (int kb = 0; kb < KBC; ++kb) a[kb] = *reinterpret_cast<const f32x4 *>(xr + kb * 8);
+#pragma unroll
+      for (int kb = 0; kb < KBC; ++kb)
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int i = 0; i < NTW; ++i)
-            acc[mi][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[i][kb][s], acc[mi][i], 0, 0, 0);
+            acc[mi][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kb][s], b[i][kb][s], acc[mi][i], 0, 0, 0);
+      if constexpr (KBC > 2) {   // same read-ahead ladder as run_layer
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int kb = 0; kb < KBC - 2; ++kb) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 4 * NTW, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 * NTW, 0);
       }
     }
   }

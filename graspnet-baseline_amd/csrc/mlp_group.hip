@@ -7,6 +7,8 @@
 // the pooled result in HBM (2.1 GB for CloudCrop at batch 8); here a persistent workgroup gathers a
 // tile of TP neighbour rows straight into LDS, runs the three layers on fp32 MFMA with the weights
 // resident in registers (mlp_core.h) and writes only the pooled (group, C3) rows.
+#include <stdlib.h>
+
 #include "mlp_core.h"
 
 namespace gn {
@@ -96,12 +98,17 @@ __global__ __launch_bounds__(MLP_THREADS) void sa_mlp_kernel(const float *__rest
 }
 
 // ---- cloud crop --------------------------------------------------------------------------------
-template <int C1, int C2, int C3, int NS, int ND, int TP>
-__global__ __launch_bounds__(MLP_THREADS) void crop_mlp_kernel(const float *__restrict__ xyz, int n,
-                                                               const float *__restrict__ seed,
-                                                               const float *__restrict__ rot,
-                                                               const int32_t *__restrict__ idx, int m, int ntiles,
-                                                               int tpb, Mlp3Weights W, float *__restrict__ out) {
+// MINW = waves per SIMD the register allocation must allow (2 => two workgroups per CU, so one
+// workgroup's gather / LDS epilogues / barriers hide behind the other's MFMAs).
+// RES12 = keep layers 1-2 resident in registers too (else they are re-read from L2 per tile; only
+// the 256x128 last layer, 80 % of the FLOPs, stays resident).
+template <int C1, int C2, int C3, int NS, int ND, int TP, int MINW, bool RES12>
+__global__ __launch_bounds__(MLP_THREADS, MINW) void crop_mlp_kernel(const float *__restrict__ xyz, int n,
+                                                                     const float *__restrict__ seed,
+                                                                     const float *__restrict__ rot,
+                                                                     const int32_t *__restrict__ idx, int m,
+                                                                     int ntiles, int tpb, Mlp3Weights W,
+                                                                     float *__restrict__ out) {
   constexpr int CIN0 = 8;
   constexpr int GPT = TP / NS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -112,8 +119,10 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_mlp_kernel(const float *__re
   LayerW<CIN0, C1> w1;
   LayerW<C1, C2> w2;
   LayerW<C2, C3> w3;
-  w1.load(W.w1, W.b1, wave, lane);
-  w2.load(W.w2, W.b2, wave, lane);
+  if (RES12) {
+    w1.load(W.w1, W.b1, wave, lane);
+    w2.load(W.w2, W.b2, wave, lane);
+  }
   w3.load(W.w3, W.b3, wave, lane);
 
   const int gpc = m * ND;  // groups per cloud
@@ -121,12 +130,11 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_mlp_kernel(const float *__re
   for (int tile = blockIdx.x * tpb; tile < tile_end; ++tile) {
     const int g0 = tile * GPT;
     const int b = g0 / gpc;
-    const int gl = g0 - b * gpc;  // first group within the cloud
-    // tile groups are consecutive [seed][depth] entries of one cloud; pass seed/rot bases of the
-    // cloud and a local group offset folded into the row index
+    const int gl = g0 - b * gpc;  // first group within the cloud; groups are [seed][depth]
     const float *seed_b = seed + (size_t)b * m * 3;
     const float *rot_b = rot + (size_t)b * m * 9;
     {
+      // rows: [ (xyz[src]-seed)^T R (3) | 0-pad to 8 ]   (pointnet2_utils.py:524-530)
       constexpr int XS = lds_stride(8);
       const int32_t *ix = idx + (size_t)g0 * NS;
       const float *px = xyz + (size_t)b * n * 3;
@@ -149,9 +157,11 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_mlp_kernel(const float *__re
     }
     __syncthreads();
     StoreLds<true> e1{bufB, lds_stride(C1), C1, lane};
+    if (!RES12) w1.load(W.w1, W.b1, wave, lane);
     run_layer<TP, CIN0, C1>(w1, bufA, wave, lane, e1);
     __syncthreads();
     StoreLds<true> e2{bufA, lds_stride(C2), C2, lane};
+    if (!RES12) w2.load(W.w2, W.b2, wave, lane);
     run_layer<TP, C1, C2>(w2, bufB, wave, lane, e2);
     __syncthreads();
     PoolGlobal<NS, LayerW<C2, C3>::NTW> e3{out + (size_t)g0 * C3, C3, lane, {}};
@@ -240,17 +250,27 @@ extern "C" int gn_crop_group_mlp_pool(const float *xyz, const float *seed_xyz, c
               mlp[1], mlp[2]);
     return GN_ERR_INVALID_ARG;
   }
-  constexpr int TP = 128, NS = 64, ND = 4;
-  GN_REQUIRE((m * ND) % (TP / NS) == 0, "crop_group_mlp_pool: bad seed count");
+  constexpr int NS = 64, ND = 4;
   const Mlp3Weights W{wpacked[0], bias[0], wpacked[1], bias[1], wpacked[2], bias[2]};
-  const int ntiles = (int)((long)b * m * ND / (TP / NS));
-  constexpr size_t lds = sizeof(float) * group_mlp_lds_floats<8, 64, 128, TP>();
-  auto k = crop_mlp_kernel<64, 128, 256, NS, ND, TP>;
-  int rc = set_lds(k, lds, "crop_group_mlp_pool");
+  static const int variant = []() { const char *e = getenv("GN_CROP_VARIANT"); return e ? atoi(e) : 0; }();
+  auto launch = [&](auto kernel, int tp, size_t lds) -> int {
+    if ((m * ND) % (tp / NS) != 0) { set_error("crop_group_mlp_pool: bad seed count"); return GN_ERR_INVALID_ARG; }
+    const int ntiles = (int)((long)b * m * ND / (tp / NS));
+    int rc = set_lds(kernel, lds, "crop_group_mlp_pool");
+    if (rc) return rc;
+    const int tpb = tiles_per_block(ntiles);
+    hipLaunchKernelGGL(kernel, dim3((ntiles + tpb - 1) / tpb), dim3(MLP_THREADS), lds, as_stream(stream), xyz, n,
+                       seed_xyz, rot, idx, m, ntiles, tpb, W, out);
+    return GN_OK;
+  };
+  int rc;
+  if (variant == 1)
+    rc = launch(crop_mlp_kernel<64, 128, 256, NS, ND, 64, 2, false>, 64,
+                sizeof(float) * group_mlp_lds_floats<8, 64, 128, 64>());
+  else
+    rc = launch(crop_mlp_kernel<64, 128, 256, NS, ND, 128, 1, true>, 128,
+                sizeof(float) * group_mlp_lds_floats<8, 64, 128, 128>());
   if (rc) return rc;
-  const int tpb = tiles_per_block(ntiles);
-  hipLaunchKernelGGL(k, dim3((ntiles + tpb - 1) / tpb), dim3(MLP_THREADS), lds, as_stream(stream), xyz, n, seed_xyz,
-                     rot, idx, m, ntiles, tpb, W, out);
   GN_CHECK_LAUNCH("crop_group_mlp_pool");
   return GN_OK;
 }

@@ -167,7 +167,7 @@ extern "C" int gn_approach_mlp(const float *x, int rows, int cin, int nout, cons
   PointMlpArgs a{};
   a.w1 = wpacked[0]; a.b1 = bias[0]; a.w2 = wpacked[1]; a.b2 = bias[1]; a.w3 = wpacked[2]; a.b3 = bias[2];
   a.x = x; a.out = out; a.ldo = 302; a.ncols_out = 302; a.nrows = rows;
-  return launch_point_mlp<LOAD_PLAIN, 256, 256, 256, 384, 304, 384, 128, 128, 152, 64, false>(a, as_stream(stream),
+  return launch_point_mlp<LOAD_PLAIN, 256, 256, 256, 384, 320, 384, 128, 64, 80, 64, false>(a, as_stream(stream),
                                                                                              "approach_mlp");
 }
 

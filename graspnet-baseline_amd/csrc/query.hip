@@ -36,14 +36,21 @@ __global__ __launch_bounds__(QUERY_WAVES * 64) void query_kernel(
 
   int cnt = 0;
   int first = 0;
-  for (int k0 = 0; k0 < n && cnt < nsample; k0 += 64) {
-    const int k = k0 + lane;
-    bool hit = false;
-    if (k < n) {
-      const float px = xyz[k * 3 + 0], py = xyz[k * 3 + 1], pz = xyz[k * 3 + 2];
+  constexpr int U = 4;  // 64-point chunks per iteration: their loads are issued together (latency overlap)
+  for (int k0 = 0; k0 < n && cnt < nsample; k0 += 64 * U) {
+    float px[U], py[U], pz[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = min(k0 + u * 64 + lane, n - 1);
+      px[u] = xyz[k * 3 + 0]; py[u] = xyz[k * 3 + 1]; pz[u] = xyz[k * 3 + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + u * 64 + lane;
+      bool hit;
       if (CYL) {
         // cylinder_query_gpu.cu:36-46
-        const float x = px - cx, y = py - cy, z = pz - cz;
+        const float x = px[u] - cx, y = py[u] - cy, z = pz[u] - cz;
         const float x_rot = r0 * x + r3 * y + r6 * z;
         const float y_rot = r1 * x + r4 * y + r7 * z;
         const float z_rot = r2 * x + r5 * y + r8 * z;
@@ -51,17 +58,18 @@ __global__ __launch_bounds__(QUERY_WAVES * 64) void query_kernel(
         hit = d2 < radius2 && x_rot > hmin && x_rot < hmax;
       } else {
         // ball_query_gpu.cu:33-38
-        const float d2 = (cx - px) * (cx - px) + (cy - py) * (cy - py) + (cz - pz) * (cz - pz);
+        const float d2 = (cx - px[u]) * (cx - px[u]) + (cy - py[u]) * (cy - py[u]) + (cz - pz[u]) * (cz - pz[u]);
         hit = d2 < radius2;
       }
-    }
-    const unsigned long long mask = __ballot(hit);
-    if (mask) {
-      if (cnt == 0) first = k0 + __ffsll((long long)mask) - 1;
-      const int slot = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                       __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-      if (hit && slot < nsample) row[slot] = k;
-      cnt += __popcll(mask);
+      hit = hit && k < n;
+      const unsigned long long mask = __ballot(hit);
+      if (mask && cnt < nsample) {
+        if (cnt == 0) first = k0 + u * 64 + __ffsll((long long)mask) - 1;
+        const int slot = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        if (hit && slot < nsample) row[slot] = k;
+        cnt += __popcll(mask);
+      }
     }
   }
   // unfilled slots repeat the first hit (ball_query_gpu.cu:39-43); no hit -> zeros
@@ -93,33 +101,39 @@ __global__ __launch_bounds__(QUERY_WAVES * 64) void cylinder_multi_kernel(
   int cnt[ND], first[ND];
 #pragma unroll
   for (int d = 0; d < ND; ++d) { cnt[d] = 0; first[d] = 0; }
-  for (int k0 = 0; k0 < n; k0 += 64) {
+  constexpr int U = 4;
+  for (int k0 = 0; k0 < n; k0 += 64 * U) {
     bool done = true;
 #pragma unroll
     for (int d = 0; d < ND; ++d) done = done && (cnt[d] >= nsample);
     if (done) break;
-    const int k = k0 + lane;
-    bool base = false;
-    float x_rot = 0.f;
-    if (k < n) {
-      const float x = xyz[k * 3 + 0] - cx, y = xyz[k * 3 + 1] - cy, z = xyz[k * 3 + 2] - cz;
-      x_rot = r0 * x + r3 * y + r6 * z;
+    float px[U], py[U], pz[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = min(k0 + u * 64 + lane, n - 1);
+      px[u] = xyz[k * 3 + 0]; py[u] = xyz[k * 3 + 1]; pz[u] = xyz[k * 3 + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + u * 64 + lane;
+      const float x = px[u] - cx, y = py[u] - cy, z = pz[u] - cz;
+      const float x_rot = r0 * x + r3 * y + r6 * z;
       const float y_rot = r1 * x + r4 * y + r7 * z;
       const float z_rot = r2 * x + r5 * y + r8 * z;
       const float d2 = y_rot * y_rot + z_rot * z_rot;
-      base = d2 < radius2 && x_rot > hmin;
-    }
-    if (!__ballot(base)) continue;
+      const bool base = d2 < radius2 && x_rot > hmin && k < n;
+      if (!__ballot(base)) continue;
 #pragma unroll
-    for (int d = 0; d < ND; ++d) {
-      const bool hit = base && x_rot < hmax[d];
-      const unsigned long long mask = __ballot(hit);
-      if (mask && cnt[d] < nsample) {
-        if (cnt[d] == 0) first[d] = k0 + __ffsll((long long)mask) - 1;
-        const int slot = cnt[d] + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                            __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-        if (hit && slot < nsample) row[d * nsample + slot] = k;
-        cnt[d] += __popcll(mask);
+      for (int d = 0; d < ND; ++d) {
+        const bool hit = base && x_rot < hmax[d];
+        const unsigned long long mask = __ballot(hit);
+        if (mask && cnt[d] < nsample) {
+          if (cnt[d] == 0) first[d] = k0 + u * 64 + __ffsll((long long)mask) - 1;
+          const int slot = cnt[d] + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+          if (hit && slot < nsample) row[d * nsample + slot] = k;
+          cnt[d] += __popcll(mask);
+        }
       }
     }
   }

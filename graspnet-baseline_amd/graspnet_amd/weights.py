@@ -85,7 +85,7 @@ def prepare(sd, device, num_view=300, num_angle=12):
     l3 = fold_bn(sd[vp + ".conv3.weight"], sd[vp + ".conv3.bias"], sd, None)
     nvp = coutp_for(nv)
     out["approach"] = PackedMlp([pack_fragments(*l1), pack_fragments(*l2, coutp=nvp),
-                                 pack_fragments(*l3, cinp=pad_to(nv, 8), coutp=nvp)], device)
+                                 pack_fragments(*l3, cinp=pad_to(nv, 32), coutp=nvp)], device)   # K padded to 320: chunks of 80
     out["crop"] = PackedMlp([pack_fragments(w, b, cinp=8 if i == 0 else None)
                              for i, (w, b) in enumerate(_shared_mlp_layers(sd, "grasp_generator.crop.mlps", 3))], device)
     # OperationNet + ToleranceNet as one chain: conv1 stacked, conv2 / conv3 block-diagonal

@@ -159,15 +159,49 @@ struct PoolGlobal {
   }
 };
 
+// ReLU + max over the rows of a ragged row set, each row contributing to the depths named by its
+// ND-bit mask (smask[row], LDS).  hold[][] persists over M tiles / chunks; finish() writes
+// out[d*ldo_d + col].  Rows with mask 0 (tile padding) contribute nothing.
+template <int ND, int NTW>
+struct PoolMasked {
+  const int *smask;
+  int lane;
+  float hold[ND][NTW];
+  __device__ __forceinline__ void reset() {
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) hold[d][i] = -INFINITY;
+  }
+  __device__ __forceinline__ void operator()(int mt, int /*nt*/, int i, const f32x16 &acc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int mk = smask[mt * 32 + acc_row(r, lane)];
+#pragma unroll
+      for (int d = 0; d < ND; ++d) hold[d][i] = ((mk >> d) & 1) ? fmaxf(hold[d][i], acc[r]) : hold[d][i];
+    }
+  }
+  // out points at the seed's first depth row; depth rows are `ldo` floats apart
+  __device__ __forceinline__ void finish(float *out, int ldo, int nt0) {
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        const float v = xhalf_max(hold[d][i], lane);
+        if (lane < 32) out[(size_t)d * ldo + (nt0 + i) * 32 + lane] = fmaxf(v, 0.f);
+      }
+  }
+};
+
 // ---- one layer over a TP-position LDS tile, weights resident --------------------------------
 template <int TP, int CINP, int COUTP, class Epi>
 __device__ __forceinline__ void run_layer(const LayerW<CINP, COUTP> &w, const float *__restrict__ xs, int wave,
-                                          int lane, Epi &epi) {
+                                          int lane, Epi &epi, int mt_count = TP / 32) {
   using LW = LayerW<CINP, COUTP>;
   constexpr int XS = lds_stride(CINP);
   const int wm = wave / LW::WN;
   const int wn = wave % LW::WN;
-  for (int mt = wm; mt < TP / 32; mt += LW::WM) {
+  for (int mt = wm; mt < mt_count; mt += LW::WM) {
     f32x16 acc[LW::NTW];
 #pragma unroll
     for (int i = 0; i < LW::NTW; ++i)

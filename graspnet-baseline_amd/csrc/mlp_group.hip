@@ -170,6 +170,81 @@ __global__ __launch_bounds__(MLP_THREADS, MINW) void crop_mlp_kernel(const float
   }
 }
 
+// ---- cloud crop over the UNIQUE rows of each seed (gn_cylinder_query_unique) ----------------------
+// One seed = one ragged row set (<= ND*NS entries, typically ~90): rows are evaluated once and
+// max-pooled into the depths named by their mask.  2.3-2.5x fewer MFMAs than pooling ND full lists,
+// same bits.  A workgroup walks `spb` consecutive seeds with all weights resident.
+template <int C1, int C2, int C3, int ND, int CAP>
+__global__ __launch_bounds__(MLP_THREADS) void crop_unique_mlp_kernel(const float *__restrict__ xyz, int n,
+                                                                      const float *__restrict__ seed,
+                                                                      const float *__restrict__ rot,
+                                                                      const int32_t *__restrict__ uidx,
+                                                                      const int32_t *__restrict__ ucount, int m,
+                                                                      int nseeds, int spb, Mlp3Weights W,
+                                                                      float *__restrict__ out) {
+  constexpr int CIN0 = 8, TP = 128;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *bufA = smem;
+  float *bufB = smem + cmax(TP * lds_stride(CIN0), TP * lds_stride(C2));
+  int *smask = reinterpret_cast<int *>(bufB + TP * lds_stride(C1));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  LayerW<CIN0, C1> w1;
+  LayerW<C1, C2> w2;
+  LayerW<C2, C3> w3;
+  w1.load(W.w1, W.b1, wave, lane);
+  w2.load(W.w2, W.b2, wave, lane);
+  w3.load(W.w3, W.b3, wave, lane);
+  using L3 = LayerW<C2, C3>;
+  PoolMasked<ND, L3::NTW> pool{smask, lane, {}};
+
+  const int s_end = min(nseeds, (int)(blockIdx.x + 1) * spb);
+  for (int sf = blockIdx.x * spb; sf < s_end; ++sf) {
+    const int b = sf / m;
+    const int nu = ucount[sf];
+    const float *c = seed + (size_t)sf * 3;
+    const float *r = rot + (size_t)sf * 9;
+    const float *px = xyz + (size_t)b * n * 3;
+    const int32_t *ue = uidx + (size_t)sf * CAP;
+    pool.reset();
+    for (int row0 = 0; row0 < nu; row0 += TP) {
+      const int rows = min(TP, nu - row0);
+      const int mtc = (rows + 31) >> 5;
+      {
+        constexpr int XS = lds_stride(8);
+        for (int p = tid; p < mtc * 32; p += MLP_THREADS) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          int mk = 0;
+          if (p < rows) {
+            const int e = ue[row0 + p];
+            const int src = e & 0x0fffffff;
+            mk = (int)((unsigned)e >> 28);
+            const float x = px[src * 3 + 0] - c[0];
+            const float y = px[src * 3 + 1] - c[1];
+            const float z = px[src * 3 + 2] - c[2];
+            v[0] = x * r[0] + y * r[3] + z * r[6];   // (p-c)^T R, pointnet2_utils.py:528-530
+            v[1] = x * r[1] + y * r[4] + z * r[7];
+            v[2] = x * r[2] + y * r[5] + z * r[8];
+          }
+          *reinterpret_cast<f32x4 *>(bufA + p * XS) = v;
+          *reinterpret_cast<f32x4 *>(bufA + p * XS + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+          smask[p] = mk;
+        }
+      }
+      __syncthreads();
+      StoreLds<true> e1{bufB, lds_stride(C1), C1, lane};
+      run_layer<TP, CIN0, C1>(w1, bufA, wave, lane, e1, mtc);
+      __syncthreads();
+      StoreLds<true> e2{bufA, lds_stride(C2), C2, lane};
+      run_layer<TP, C1, C2>(w2, bufB, wave, lane, e2, mtc);
+      __syncthreads();
+      run_layer<TP, C2, C3>(w3, bufA, wave, lane, pool, mtc);
+      __syncthreads();
+    }
+    pool.finish(out + (size_t)sf * ND * C3, C3, (wave % L3::WN) * L3::NTW);
+  }
+}
+
 // tiles per block: amortise the per-block weight load over up to 8 tiles while keeping >= ~4 blocks
 // per CU in the grid (dynamic balance, and room for concurrent streams)
 static int tiles_per_block(int ntiles) {
@@ -272,5 +347,34 @@ extern "C" int gn_crop_group_mlp_pool(const float *xyz, const float *seed_xyz, c
                 sizeof(float) * group_mlp_lds_floats<8, 64, 128, 128>());
   if (rc) return rc;
   GN_CHECK_LAUNCH("crop_group_mlp_pool");
+  return GN_OK;
+}
+
+extern "C" int gn_crop_unique_mlp_pool(const float *xyz, const float *seed_xyz, const float *rot, const int32_t *uidx,
+                                       const int32_t *ucount, int b, int n, int m, int ndepth, int ns, const int *mlp,
+                                       const float *const *wpacked, const float *const *bias, float *out,
+                                       gn_stream_t stream) {
+  GN_REQUIRE(b >= 0 && n > 0 && m > 0, "crop_unique_mlp_pool: bad sizes");
+  if (b == 0) return GN_OK;
+  GN_REQUIRE(xyz && seed_xyz && rot && uidx && ucount && mlp && wpacked && bias && out,
+             "crop_unique_mlp_pool: null pointer");
+  GN_REQUIRE((long)n * 3 < 0x7fffffffL, "crop_unique_mlp_pool: n too large");
+  if (!(ndepth == 4 && ns == 64 && mlp[0] == 64 && mlp[1] == 128 && mlp[2] == 256)) {
+    set_error("crop_unique_mlp_pool: unsupported configuration depth=%d nsample=%d mlp=[%d,%d,%d]", ndepth, ns,
+              mlp[0], mlp[1], mlp[2]);
+    return GN_ERR_INVALID_ARG;
+  }
+  const Mlp3Weights W{wpacked[0], bias[0], wpacked[1], bias[1], wpacked[2], bias[2]};
+  constexpr int TP = 128;
+  constexpr size_t lds = sizeof(float) * (group_mlp_lds_floats<8, 64, 128, TP>() + TP);
+  auto k = crop_unique_mlp_kernel<64, 128, 256, 4, 256>;
+  int rc = set_lds(k, lds, "crop_unique_mlp_pool");
+  if (rc) return rc;
+  const int nseeds = b * m;
+  int spb = nseeds / 2048;   // >= ~8 workgroups per CU in the grid; weights amortised over spb seeds
+  spb = spb < 1 ? 1 : (spb > 8 ? 8 : spb);
+  hipLaunchKernelGGL(k, dim3((nseeds + spb - 1) / spb), dim3(MLP_THREADS), lds, as_stream(stream), xyz, n, seed_xyz,
+                     rot, uidx, ucount, m, nseeds, spb, W, out);
+  GN_CHECK_LAUNCH("crop_unique_mlp_pool");
   return GN_OK;
 }

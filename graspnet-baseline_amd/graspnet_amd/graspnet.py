@@ -12,6 +12,7 @@ Differences a caller can observe:
   * weights are given as a state-dict with the reference's key layout via load_state_dict().
 """
 import ctypes
+import os
 
 import torch
 
@@ -53,6 +54,8 @@ class GraspNet:
         self._tables = None
         self._sd = None
         self.timing = None        # set to {} to collect (start,end) HIP events per kernel launch
+        # CloudCrop over de-duplicated (seed, point) rows (default) or over the four full index lists
+        self.crop_unique = os.environ.get("GN_CROP_PATH", "unique") != "lists"
 
     def _run(self, name, status_fn):
         """Issue one C-ABI call; when self.timing is a dict, bracket it with events on the launch stream."""
@@ -198,15 +201,28 @@ class GraspNet:
 
             # ---- CloudCrop (modules.py:109-141), inference branch of GraspNetStage2 (graspnet.py:53-57)
             D, NS = self.num_depth, self.crop_nsample
-            cyl_idx = torch.empty((B, M, D, NS), dtype=i32, device=dev)
-            self._run("cylinder_query_multi", lambda: lib.gn_cylinder_query_multi(seed_xyz.data_ptr(), xyz.data_ptr(), top_rot.data_ptr(), B, N, M,
-                                                self.cylinder_radius, self.hmin, self.hmax, D, NS,
-                                                cyl_idx.data_ptr(), st))
             vp = torch.empty((B, M * D, 256), dtype=f32, device=dev)
             pk = self._packed["crop"]
-            self._run("crop_group_mlp_pool", lambda: lib.gn_crop_group_mlp_pool(xyz.data_ptr(), seed_xyz.data_ptr(), top_rot.data_ptr(),
-                                               cyl_idx.data_ptr(), B, N, M, D, NS, _ci(64, 128, 256), pk.wptr, pk.bptr,
-                                               vp.data_ptr(), st))
+            if self.crop_unique:
+                # the 4 nested cylinders as one de-duplicated row list per seed (exact, ~2.4x fewer MFMAs)
+                uidx = torch.empty((B, M, D * NS), dtype=i32, device=dev)
+                ucount = torch.empty((B, M), dtype=i32, device=dev)
+                self._run("cylinder_query_unique", lambda: lib.gn_cylinder_query_unique(
+                    seed_xyz.data_ptr(), xyz.data_ptr(), top_rot.data_ptr(), B, N, M, self.cylinder_radius, self.hmin,
+                    self.hmax, D, NS, uidx.data_ptr(), ucount.data_ptr(), st))
+                self._run("crop_unique_mlp_pool", lambda: lib.gn_crop_unique_mlp_pool(
+                    xyz.data_ptr(), seed_xyz.data_ptr(), top_rot.data_ptr(), uidx.data_ptr(), ucount.data_ptr(), B, N, M,
+                    D, NS, _ci(64, 128, 256), pk.wptr, pk.bptr, vp.data_ptr(), st))
+                crop_priv = {"uidx": uidx, "ucount": ucount}
+            else:
+                cyl_idx = torch.empty((B, M, D, NS), dtype=i32, device=dev)
+                self._run("cylinder_query_multi", lambda: lib.gn_cylinder_query_multi(
+                    seed_xyz.data_ptr(), xyz.data_ptr(), top_rot.data_ptr(), B, N, M, self.cylinder_radius, self.hmin,
+                    self.hmax, D, NS, cyl_idx.data_ptr(), st))
+                self._run("crop_group_mlp_pool", lambda: lib.gn_crop_group_mlp_pool(
+                    xyz.data_ptr(), seed_xyz.data_ptr(), top_rot.data_ptr(), cyl_idx.data_ptr(), B, N, M, D, NS,
+                    _ci(64, 128, 256), pk.wptr, pk.bptr, vp.data_ptr(), st))
+                crop_priv = {"cyl_idx": cyl_idx}
 
             # ---- OperationNet + ToleranceNet (modules.py:169-191, 214-232)
             A = self.num_angle
@@ -219,7 +235,7 @@ class GraspNet:
             end_points["grasp_width_pred"] = hv[:, 2 * A:3 * A]
             end_points["grasp_tolerance_pred"] = hv[:, 3 * A:4 * A]
             # private handles for the fused decode / tests
-            end_points["_gn"] = {"feat": feat302, "head": head, "model": self, "cyl_idx": cyl_idx, "vp": vp}
+            end_points["_gn"] = dict({"feat": feat302, "head": head, "model": self, "vp": vp}, **crop_priv)
         return end_points
 
     @torch.no_grad()

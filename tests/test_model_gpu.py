@@ -155,6 +155,71 @@ def test_cylinder_multi_equals_four_queries(hip, ref, net):
         assert torch.equal(out[:, :, d], E.cylinder_query(seed, xyz, rot, 0.05, -0.02, h, 64))
 
 
+def test_cylinder_unique_reconstructs_the_four_lists(ref):
+    """de-duplicated list + masks  ->  exactly the reference's four index lists (padding and zero rows included)"""
+    rep, _ = ref
+    L = _lib()
+    xyz = rep["input_xyz"].cuda()
+    seed = rep["fp2_xyz"].cuda()
+    rot = rep["grasp_top_view_rot"].reshape(2, 1024, 9).contiguous().cuda()
+    # make a few cylinders empty / nearly empty: seeds far away from the cloud
+    seed[0, :3] += 5.0
+    hm = (ctypes.c_float * 4)(0.01, 0.02, 0.03, 0.04)
+    uidx = torch.empty((2, 1024, 256), dtype=torch.int32, device="cuda")
+    ucnt = torch.empty((2, 1024), dtype=torch.int32, device="cuda")
+    lists = torch.empty((2, 1024, 4, 64), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    L.check(L.lib().gn_cylinder_query_unique(seed.data_ptr(), xyz.data_ptr(), rot.data_ptr(), 2, 20000, 1024, 0.05, -0.02,
+                                             hm, 4, 64, uidx.data_ptr(), ucnt.data_ptr(), st), "cyl unique")
+    L.check(L.lib().gn_cylinder_query_multi(seed.data_ptr(), xyz.data_ptr(), rot.data_ptr(), 2, 20000, 1024, 0.05, -0.02,
+                                            hm, 4, 64, lists.data_ptr(), st), "cyl multi")
+    uidx, ucnt, lists = uidx.cpu().numpy(), ucnt.cpu().numpy(), lists.cpu().numpy()
+    assert ucnt.min() >= 1 and ucnt.max() <= 256
+    assert (lists[0, :3] == 0).all()                      # the far-away seeds: zero rows
+    for b in range(2):
+        for s in list(range(0, 1024, 7)) + [1, 2]:
+            e = uidx[b, s, :ucnt[b, s]]
+            k, mk = e & 0x0fffffff, (e.astype(np.uint32) >> 28)
+            assert len(np.unique(k)) == len(k)            # each point once
+            for d in range(4):
+                sel = k[(mk >> d) & 1 == 1]
+                want = np.zeros(64, np.int32)
+                want[:] = sel[0]
+                want[:len(sel)] = sel
+                assert len(sel) <= 64 and np.array_equal(want, lists[b, s, d]), (b, s, d)
+
+
+def test_crop_unique_equals_crop_lists(ref, net):
+    """masked pooling over unique rows == pooling the four full lists, bit for bit"""
+    rep, _ = ref
+    L = _lib()
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    xyz = rep["input_xyz"].cuda()
+    seed = rep["fp2_xyz"].cuda()
+    rot = rep["grasp_top_view_rot"].reshape(2, 1024, 9).contiguous().cuda()
+    hm = (ctypes.c_float * 4)(0.01, 0.02, 0.03, 0.04)
+    pk = net._packed["crop"]
+    mlp = (ctypes.c_int * 3)(64, 128, 256)
+    uidx = torch.empty((2, 1024, 256), dtype=torch.int32, device="cuda")
+    ucnt = torch.empty((2, 1024), dtype=torch.int32, device="cuda")
+    lists = torch.empty((2, 1024, 4, 64), dtype=torch.int32, device="cuda")
+    L.check(lib.gn_cylinder_query_unique(seed.data_ptr(), xyz.data_ptr(), rot.data_ptr(), 2, 20000, 1024, 0.05, -0.02, hm, 4,
+                                         64, uidx.data_ptr(), ucnt.data_ptr(), st), "cyl unique")
+    L.check(lib.gn_cylinder_query_multi(seed.data_ptr(), xyz.data_ptr(), rot.data_ptr(), 2, 20000, 1024, 0.05, -0.02, hm, 4,
+                                        64, lists.data_ptr(), st), "cyl multi")
+    v1 = torch.empty((2, 4096, 256), device="cuda")
+    v2 = torch.empty((2, 4096, 256), device="cuda")
+    L.check(lib.gn_crop_unique_mlp_pool(xyz.data_ptr(), seed.data_ptr(), rot.data_ptr(), uidx.data_ptr(), ucnt.data_ptr(), 2,
+                                        20000, 1024, 4, 64, mlp, pk.wptr, pk.bptr, v1.data_ptr(), st), "crop unique")
+    L.check(lib.gn_crop_group_mlp_pool(xyz.data_ptr(), seed.data_ptr(), rot.data_ptr(), lists.data_ptr(), 2, 20000, 1024, 4,
+                                       64, mlp, pk.wptr, pk.bptr, v2.data_ptr(), st), "crop lists")
+    assert torch.equal(v1, v2)
+    want = rep["_vp_features"].reshape(2, 256, 4096).transpose(1, 2)
+    close(v1, want, "vp_features (unique path)")
+    print("unique rows per seed: mean %.1f max %d" % (float(ucnt.float().mean()), int(ucnt.max())))
+
+
 def test_crop_and_heads_isolated(ref, net):
     """CloudCrop + heads on the ORACLE's seeds/rotations/indices (no upstream flips)."""
     rep, _ = ref

@@ -160,11 +160,14 @@ struct PoolGlobal {
 };
 
 // ReLU + max over the rows of a ragged row set, each row contributing to the depths named by its
-// ND-bit mask (smask[row], LDS).  hold[][] persists over M tiles / chunks; finish() writes
-// out[d*ldo_d + col].  Rows with mask 0 (tile padding) contribute nothing.
+// ND-bit mask.  The loader stores the mask as ND additive gates per row (0 = member, -inf = not):
+// acc + gate is exact for members and -inf otherwise, so pooling is one add + one max per
+// (row, depth) with no bit tests.  hold[][] persists over M tiles / chunks; finish() writes the
+// ReLU'd maxima.  Tile-padding rows carry all -inf gates.
 template <int ND, int NTW>
 struct PoolMasked {
-  const int *smask;
+  static_assert(ND == 4, "gates are stored as one float4 per row");
+  const float *sgate;   // LDS, [row][4]
   int lane;
   float hold[ND][NTW];
   __device__ __forceinline__ void reset() {
@@ -175,10 +178,11 @@ struct PoolMasked {
   }
   __device__ __forceinline__ void operator()(int mt, int /*nt*/, int i, const f32x16 &acc) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int mk = smask[mt * 32 + acc_row(r, lane)];
+    for (int r = 0; r < 16; r += 2) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4 *>(sgate + (mt * 32 + acc_row(r, lane)) * 4);
+      const f32x4 g1 = *reinterpret_cast<const f32x4 *>(sgate + (mt * 32 + acc_row(r + 1, lane)) * 4);
 #pragma unroll
-      for (int d = 0; d < ND; ++d) hold[d][i] = ((mk >> d) & 1) ? fmaxf(hold[d][i], acc[r]) : hold[d][i];
+      for (int d = 0; d < ND; ++d) hold[d][i] = fmaxf(hold[d][i], fmaxf(acc[r] + g0[d], acc[r + 1] + g1[d]));
     }
   }
   // out points at the seed's first depth row; depth rows are `ldo` floats apart

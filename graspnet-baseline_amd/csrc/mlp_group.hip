@@ -173,7 +173,10 @@ __global__ __launch_bounds__(MLP_THREADS, MINW) void crop_mlp_kernel(const float
 // ---- cloud crop over the UNIQUE rows of each seed (gn_cylinder_query_unique) ----------------------
 // One seed = one ragged row set (<= ND*NS entries, typically ~90): rows are evaluated once and
 // max-pooled into the depths named by their mask.  2.3-2.5x fewer MFMAs than pooling ND full lists,
-// same bits.  A workgroup walks `spb` consecutive seeds with all weights resident.
+// same bits.  A workgroup walks `spb` consecutive seeds with all weights resident; the work is a
+// sequence of <=128-row chunks, and the NEXT chunk's rows (index -> xyz gather -> rotate) are
+// fetched into registers while the current chunk runs through the three layers, then dropped into
+// the other half of a double-buffered LDS input tile.
 template <int C1, int C2, int C3, int ND, int CAP>
 __global__ __launch_bounds__(MLP_THREADS) void crop_unique_mlp_kernel(const float *__restrict__ xyz, int n,
                                                                       const float *__restrict__ seed,
@@ -182,11 +185,12 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_unique_mlp_kernel(const floa
                                                                       const int32_t *__restrict__ ucount, int m,
                                                                       int nseeds, int spb, Mlp3Weights W,
                                                                       float *__restrict__ out) {
-  constexpr int CIN0 = 8, TP = 128;
+  constexpr int CIN0 = 8, TP = 128, XS0 = lds_stride(CIN0);
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *bufA = smem;
-  float *bufB = smem + cmax(TP * lds_stride(CIN0), TP * lds_stride(C2));
-  int *smask = reinterpret_cast<int *>(bufB + TP * lds_stride(C1));
+  float *bufY2 = smem;                                  // [TP][C2+4]
+  float *bufY1 = bufY2 + TP * lds_stride(C2);           // [TP][C1+4]
+  float *bufX = bufY1 + TP * lds_stride(C1);            // 2 x [TP][12]
+  float *bufG = bufX + 2 * TP * XS0;                    // 2 x [TP][4] pooling gates
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   LayerW<CIN0, C1> w1;
@@ -196,52 +200,81 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_unique_mlp_kernel(const floa
   w2.load(W.w2, W.b2, wave, lane);
   w3.load(W.w3, W.b3, wave, lane);
   using L3 = LayerW<C2, C3>;
-  PoolMasked<ND, L3::NTW> pool{smask, lane, {}};
+  PoolMasked<ND, L3::NTW> pool{bufG, lane, {}};
+  pool.reset();
 
   const int s_end = min(nseeds, (int)(blockIdx.x + 1) * spb);
-  for (int sf = blockIdx.x * spb; sf < s_end; ++sf) {
-    const int b = sf / m;
-    const int nu = ucount[sf];
-    const float *c = seed + (size_t)sf * 3;
-    const float *r = rot + (size_t)sf * 9;
-    const float *px = xyz + (size_t)b * n * 3;
-    const int32_t *ue = uidx + (size_t)sf * CAP;
-    pool.reset();
-    for (int row0 = 0; row0 < nu; row0 += TP) {
-      const int rows = min(TP, nu - row0);
-      const int mtc = (rows + 31) >> 5;
-      {
-        constexpr int XS = lds_stride(8);
-        for (int p = tid; p < mtc * 32; p += MLP_THREADS) {
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          int mk = 0;
-          if (p < rows) {
-            const int e = ue[row0 + p];
-            const int src = e & 0x0fffffff;
-            mk = (int)((unsigned)e >> 28);
-            const float x = px[src * 3 + 0] - c[0];
-            const float y = px[src * 3 + 1] - c[1];
-            const float z = px[src * 3 + 2] - c[2];
-            v[0] = x * r[0] + y * r[3] + z * r[6];   // (p-c)^T R, pointnet2_utils.py:528-530
-            v[1] = x * r[1] + y * r[4] + z * r[7];
-            v[2] = x * r[2] + y * r[5] + z * r[8];
-          }
-          *reinterpret_cast<f32x4 *>(bufA + p * XS) = v;
-          *reinterpret_cast<f32x4 *>(bufA + p * XS + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-          smask[p] = mk;
-        }
-      }
-      __syncthreads();
-      StoreLds<true> e1{bufB, lds_stride(C1), C1, lane};
-      run_layer<TP, CIN0, C1>(w1, bufA, wave, lane, e1, mtc);
-      __syncthreads();
-      StoreLds<true> e2{bufA, lds_stride(C2), C2, lane};
-      run_layer<TP, C1, C2>(w2, bufB, wave, lane, e2, mtc);
-      __syncthreads();
-      run_layer<TP, C2, C3>(w3, bufA, wave, lane, pool, mtc);
-      __syncthreads();
+  // chunk cursor: seed sf, first row row0, seed's entry count nu
+  int sf = blockIdx.x * spb;
+  if (sf >= s_end) return;
+  int nu = ucount[sf], row0 = 0;
+
+  // row p of the chunk (sf,row0): gather + rotate; returns the LDS row and its gates
+  auto fetch = [&](int csf, int crow0, int cnu, int p, f32x4 &v, f32x4 &g) {
+    v = f32x4{0.f, 0.f, 0.f, 0.f};
+    g = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (crow0 + p < cnu) {
+      const int e = uidx[(size_t)csf * CAP + crow0 + p];
+      const int src = e & 0x0fffffff;
+      const unsigned mk = (unsigned)e >> 28;
+      const float *c = seed + (size_t)csf * 3;
+      const float *r = rot + (size_t)csf * 9;
+      const float *px = xyz + (size_t)(csf / m) * n * 3;
+      const float x = px[src * 3 + 0] - c[0];
+      const float y = px[src * 3 + 1] - c[1];
+      const float z = px[src * 3 + 2] - c[2];
+      v[0] = x * r[0] + y * r[3] + z * r[6];   // (p-c)^T R, pointnet2_utils.py:528-530
+      v[1] = x * r[1] + y * r[4] + z * r[7];
+      v[2] = x * r[2] + y * r[5] + z * r[8];
+#pragma unroll
+      for (int d = 0; d < ND; ++d) g[d] = ((mk >> d) & 1u) ? 0.f : -INFINITY;
     }
-    pool.finish(out + (size_t)sf * ND * C3, C3, (wave % L3::WN) * L3::NTW);
+  };
+  auto put = [&](int buf, int p, const f32x4 &v, const f32x4 &g) {
+    float *x = bufX + buf * TP * XS0 + p * XS0;
+    *reinterpret_cast<f32x4 *>(x) = v;
+    *reinterpret_cast<f32x4 *>(x + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4 *>(bufG + buf * TP * 4 + p * 4) = g;
+  };
+
+  int buf = 0;
+  {
+    f32x4 v, g;
+    if (tid < TP) { fetch(sf, row0, nu, tid, v, g); put(0, tid, v, g); }
+  }
+  __syncthreads();
+  while (true) {
+    const int rows = min(TP, nu - row0);
+    const int mtc = (rows + 31) >> 5;
+    const bool seed_done = row0 + TP >= nu;
+    // next chunk
+    int nsf = sf, nrow0 = row0 + TP, nnu = nu;
+    if (seed_done) {
+      nsf = sf + 1;
+      nrow0 = 0;
+      nnu = nsf < s_end ? ucount[nsf] : 0;
+    }
+    const bool has_next = nsf < s_end;
+    f32x4 nv, ng;
+    if (has_next && tid < TP) fetch(nsf, nrow0, nnu, tid, nv, ng);   // in flight during the layers below
+
+    pool.sgate = bufG + buf * TP * 4;
+    StoreLds<true> e1{bufY1, lds_stride(C1), C1, lane};
+    run_layer<TP, CIN0, C1>(w1, bufX + buf * TP * XS0, wave, lane, e1, mtc);
+    __syncthreads();
+    StoreLds<true> e2{bufY2, lds_stride(C2), C2, lane};
+    run_layer<TP, C1, C2>(w2, bufY1, wave, lane, e2, mtc);
+    __syncthreads();
+    run_layer<TP, C2, C3>(w3, bufY2, wave, lane, pool, mtc);
+    if (seed_done) {
+      pool.finish(out + (size_t)sf * ND * C3, C3, (wave % L3::WN) * L3::NTW);
+      pool.reset();
+    }
+    if (!has_next) break;
+    if (tid < TP) put(buf ^ 1, tid, nv, ng);
+    __syncthreads();   // next input tile visible; Y1/Y2 free
+    buf ^= 1;
+    sf = nsf; row0 = nrow0; nu = nnu;
   }
 }
 
@@ -366,7 +399,7 @@ extern "C" int gn_crop_unique_mlp_pool(const float *xyz, const float *seed_xyz, 
   }
   const Mlp3Weights W{wpacked[0], bias[0], wpacked[1], bias[1], wpacked[2], bias[2]};
   constexpr int TP = 128;
-  constexpr size_t lds = sizeof(float) * (group_mlp_lds_floats<8, 64, 128, TP>() + TP);
+  constexpr size_t lds = sizeof(float) * (TP * lds_stride(128) + TP * lds_stride(64) + 2 * TP * lds_stride(8) + 2 * TP * 4);
   auto k = crop_unique_mlp_kernel<64, 128, 256, 4, 256>;
   int rc = set_lds(k, lds, "crop_unique_mlp_pool");
   if (rc) return rc;

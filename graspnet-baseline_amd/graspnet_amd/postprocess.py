@@ -1,0 +1,124 @@
+"""Device-side front end and post-processing around the network.
+
+  depth_to_cloud                 utils/data_utils.py:18-43 (+ picking the sampled pixels)
+  ModelFreeCollisionDetector     utils/collision_detector.py:10-129 (same constructor / detect() arguments)
+  sort_and_nms                   graspnetAPI GraspGroup.sort_by_score() / .nms()  [un-vendored, parity unpinned]
+
+Everything works on the padded (B,M,17) grasp rows + counts that GraspNet.decode_padded() leaves on
+the device, so the reference's device->host copy before collision checking (test.py:88-96) disappears.
+"""
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def depth_to_cloud(depth, fx, fy, cx, cy, factor_depth, pix_idx):
+    """depth (H,W) uint16 CUDA tensor (or int16 view of it), pix_idx (N,) int32 flat pixel indices -> (N,3) f32."""
+    if not depth.is_cuda:
+        raise RuntimeError("CPU not supported")
+    if depth.dtype not in (torch.uint16, torch.int16) or not depth.is_contiguous():
+        raise RuntimeError("depth must be a contiguous 16-bit tensor")
+    pix_idx = pix_idx.to(device=depth.device, dtype=torch.int32).contiguous()
+    h, w = depth.shape
+    out = torch.empty((pix_idx.numel(), 3), dtype=torch.float32, device=depth.device)
+    with torch.cuda.device(depth.device):
+        L.check(L.lib().gn_depth_to_cloud(depth.data_ptr(), h, w, float(fx), float(fy), float(cx), float(cy),
+                                          float(factor_depth), pix_idx.data_ptr(), pix_idx.numel(), out.data_ptr(),
+                                          _stream(depth)), "depth_to_cloud")
+    return out
+
+
+def voxel_down_sample(points, voxel_size):
+    """(N,3) f32 CUDA -> (Nv,3) f64 CUDA voxel means (one host sync for Nv)."""
+    if not points.is_cuda:
+        raise RuntimeError("CPU not supported")
+    points = points.to(torch.float32).contiguous()
+    n = points.shape[0]
+    lib = L.lib()
+    ws = torch.empty((lib.gn_voxel_workspace_bytes(n),), dtype=torch.uint8, device=points.device)
+    out = torch.empty((max(n, 1), 3), dtype=torch.float64, device=points.device)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=points.device)
+    with torch.cuda.device(points.device):
+        L.check(lib.gn_voxel_down_sample(points.data_ptr(), n, float(voxel_size), ws.data_ptr(), out.data_ptr(),
+                                         cnt.data_ptr(), _stream(points)), "voxel_down_sample")
+    err = ws[4:8].view(torch.int32)
+    nv, e = int(cnt.item()), int(err.item())
+    if e:
+        raise RuntimeError("voxel_down_sample: voxel grid exceeds 2^21 cells per axis or table overflow (code %d)" % e)
+    return out[:nv]
+
+
+class ModelFreeCollisionDetector:
+    """Same interface as utils/collision_detector.py:10-129; scene and grasps stay on the GPU."""
+
+    def __init__(self, scene_points, voxel_size=0.005, device="cuda"):
+        self.finger_width = 0.01          # collision_detector.py:29-30
+        self.finger_length = 0.06
+        self.voxel_size = voxel_size
+        if isinstance(scene_points, np.ndarray):
+            scene_points = torch.from_numpy(np.ascontiguousarray(scene_points, dtype=np.float32)).to(device)
+        self.scene_points = voxel_down_sample(scene_points, voxel_size).contiguous()
+
+    def detect_padded(self, grasps, counts=None, approach_dist=0.03, collision_thresh=0.05, return_empty_grasp=False,
+                      empty_thresh=0.01, return_ious=False):
+        """grasps (B,M,17) f32 CUDA, counts (B,) i32 or None -> collision mask (B,M) bool [, empty (B,M) bool][, ious (B,M,5)]"""
+        if not grasps.is_cuda:
+            raise RuntimeError("CPU not supported")
+        grasps = grasps.contiguous()
+        B, M = grasps.shape[0], grasps.shape[1]
+        dev = grasps.device
+        cm = torch.empty((B, M), dtype=torch.uint8, device=dev)
+        em = torch.empty((B, M), dtype=torch.uint8, device=dev) if return_empty_grasp else None
+        io = torch.empty((B, M, 5), dtype=torch.float32, device=dev) if return_ious else None
+        with torch.cuda.device(dev):
+            L.check(L.lib().gn_collision_detect(self.scene_points.data_ptr(), None, self.scene_points.shape[0],
+                                                grasps.data_ptr(), L.ptr(counts), B, M, float(approach_dist),
+                                                float(collision_thresh), float(empty_thresh), float(self.voxel_size),
+                                                self.finger_width, self.finger_length, cm.data_ptr(), L.ptr(em), L.ptr(io),
+                                                _stream(grasps)), "collision_detect")
+        ret = [cm.bool()]
+        if return_empty_grasp:
+            ret.append(em.bool())
+        if return_ious:
+            ret.append(io)
+        return ret[0] if len(ret) == 1 else ret
+
+    def detect(self, grasp_group, approach_dist=0.03, collision_thresh=0.05, return_empty_grasp=False, empty_thresh=0.01,
+               return_ious=False):
+        """grasp_group: (M,17) tensor / ndarray, or an object with `.grasp_group_array` (graspnetAPI.GraspGroup)."""
+        arr = getattr(grasp_group, "grasp_group_array", grasp_group)
+        was_numpy = isinstance(arr, np.ndarray)
+        g = torch.as_tensor(arr, dtype=torch.float32).to(self.scene_points.device).reshape(1, -1, 17)
+        res = self.detect_padded(g, None, approach_dist, collision_thresh, return_empty_grasp, empty_thresh, return_ious)
+        res = res if isinstance(res, list) else [res]
+        res = [r[0] for r in res]
+        if return_ious:      # reference returns a list of 5 (M,) arrays
+            res[-1] = [res[-1][:, i] for i in range(5)]
+        if was_numpy:
+            res = [([x.cpu().numpy() for x in r] if isinstance(r, list) else r.cpu().numpy()) for r in res]
+        return res[0] if len(res) == 1 else res
+
+
+def sort_and_nms(grasps, counts=None, drop_mask=None, translation_thresh=0.03, rotation_thresh=30.0 / 180.0 * np.pi,
+                 nms=True):
+    """(B,M,17) padded rows -> rows sorted by score (descending), optionally NMS-suppressed, padded + counts."""
+    if not grasps.is_cuda:
+        raise RuntimeError("CPU not supported")
+    grasps = grasps.contiguous()
+    B, M = grasps.shape[0], grasps.shape[1]
+    dev = grasps.device
+    lib = L.lib()
+    out = torch.empty_like(grasps)
+    oc = torch.empty((B,), dtype=torch.int32, device=dev)
+    ws = torch.empty((lib.gn_grasp_nms_workspace_bytes(B) if nms else 8,), dtype=torch.uint8, device=dev)
+    dm = None if drop_mask is None else drop_mask.to(torch.uint8).contiguous()
+    with torch.cuda.device(dev):
+        L.check(lib.gn_grasp_nms(grasps.data_ptr(), L.ptr(counts), L.ptr(dm), B, M, float(translation_thresh),
+                                 float(rotation_thresh), 1 if nms else 0, ws.data_ptr(), out.data_ptr(), oc.data_ptr(),
+                                 _stream(grasps)), "grasp_nms")
+    return out, oc

@@ -198,6 +198,42 @@ int gn_pred_decode(const float *feat, int ldf, const float *head, const int64_t 
                    const float *seed_xyz, const float *rot_table, int b, int m, int ndepth, int nangle,
                    float *grasps, int32_t *counts, gn_stream_t stream);
 
+/* ------------------------------------------------------------------ *
+ *  Around the network: front end and post-processing   *
+ * ------------------------------------------------------------------ */
+
+/* utils/data_utils.py:18-43 create_point_cloud_from_depth_image for the picked pixels:
+ * depth (H,W) u16; pix (npix) flat pixel indices (row*W+col) -> out (npix,3) f32
+ * (float64 arithmetic like numpy, z = depth/factor_depth). */
+int gn_depth_to_cloud(const uint16_t *depth, int h, int w, double fx, double fy, double cx, double cy,
+                      double factor_depth, const int32_t *pix, int npix, float *out, gn_stream_t stream);
+
+/* open3d voxel_down_sample as used by utils/collision_detector.py:32-35 (un-vendored; restated:
+ * origin = min_bound - voxel/2, voxel index = floor((p-origin)/voxel), output = mean of members in
+ * float64; output order unspecified).  out (<=n,3) f64, out_count device int. */
+size_t gn_voxel_workspace_bytes(int n);
+int gn_voxel_down_sample(const float *points, int n, double voxel_size, void *workspace, double *out,
+                         int32_t *out_count, gn_stream_t stream);
+
+/* utils/collision_detector.py:69-129 ModelFreeCollisionDetector.detect for padded grasp lists:
+ * scene_points (np,3) f64 (np read from np_dev if non-NULL), grasps (B,mpad,17) f32 rows as written
+ * by gn_pred_decode, counts (B) valid rows (NULL = all mpad).  collision_mask / empty_mask (B,mpad) u8,
+ * ious (B,mpad,5) f32 = [global,left,right,bottom,shifting]; empty_mask and ious may be NULL. */
+int gn_collision_detect(const double *scene_points, const int32_t *np_dev, int np, const float *grasps,
+                        const int32_t *counts, int b, int mpad, float approach_dist, double collision_thresh,
+                        double empty_thresh, float voxel_size, float finger_width, float finger_length,
+                        uint8_t *collision_mask, uint8_t *empty_mask, float *ious, gn_stream_t stream);
+
+/* graspnetAPI GraspGroup.sort_by_score() and .nms() (grasp_nms.nms_grasp; un-vendored, parity unpinned):
+ * rows with drop_mask != 0 (e.g. collisions; may be NULL) are removed, the rest sorted by score
+ * descending (stable) and, if do_nms, greedily suppressed when within translation_thresh (metres) AND
+ * rotation_thresh (radians, geodesic angle) of a kept grasp.  out (B,mpad,17) padded, out_counts (B).
+ * mpad <= 2048. */
+size_t gn_grasp_nms_workspace_bytes(int b);
+int gn_grasp_nms(const float *grasps, const int32_t *counts, const uint8_t *drop_mask, int b, int mpad,
+                 double translation_thresh, double rotation_thresh, int do_nms, void *workspace, float *out,
+                 int32_t *out_counts, gn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

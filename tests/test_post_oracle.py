@@ -1,0 +1,40 @@
+"""CPU: sanity of oracle/post_oracle.py (restatements around the network)."""
+import numpy as np
+
+
+def test_depth_to_cloud_formula():
+    from oracle import post_oracle as PO
+    d = np.array([[1000, 0], [500, 2000]], dtype=np.uint16)
+    c = PO.depth_to_cloud(d, 2.0, 4.0, 0.5, 0.5, 1000.0).reshape(2, 2, 3)
+    assert c.dtype == np.float64
+    assert np.allclose(c[0, 0], [(0 - 0.5) * 1.0 / 2.0, (0 - 0.5) * 1.0 / 4.0, 1.0])
+    assert np.allclose(c[1, 1], [(1 - 0.5) * 2.0 / 2.0, (1 - 0.5) * 2.0 / 4.0, 2.0])
+
+
+def test_voxel_down_sample_means():
+    from oracle import post_oracle as PO
+    p = np.array([[0, 0, 0], [0.001, 0.001, 0.001], [0.1, 0, 0]], dtype=np.float32)
+    v = PO.voxel_down_sample(p, 0.01)
+    assert v.shape == (2, 3)
+    assert any(np.allclose(r, [0.0005, 0.0005, 0.0005], atol=1e-9) for r in v)
+
+
+def test_collision_box_counts():
+    from oracle import post_oracle as PO
+    g = np.zeros((1, 17), np.float32)
+    g[0, :4] = [1.0, 0.08, 0.02, 0.02]                 # score, width, height, depth
+    g[0, 4:13] = np.eye(3, dtype=np.float32).reshape(-1)
+    # one point inside the left finger box, one far away
+    pts = np.array([[0.0, -0.045, 0.0], [1.0, 1.0, 1.0]])
+    cm, em, ious = PO.collision_detect(pts, g, approach_dist=0.03, collision_thresh=1e-9, voxel_size=0.005)
+    assert cm[0] and ious[1][0] > 0 and ious[2][0] == 0 and em[0]
+
+
+def test_nms_suppresses_near_duplicates():
+    from oracle import post_oracle as PO
+    g = np.zeros((3, 17), np.float32)
+    g[:, 4:13] = np.eye(3, dtype=np.float32).reshape(-1)
+    g[:, 0] = [0.5, 0.9, 0.1]
+    g[2, 13] = 1.0                                      # far away -> kept
+    out = PO.nms_grasp(g, 0.03, np.pi / 6)
+    assert len(out) == 2 and out[0, 0] == np.float32(0.9) and out[1, 0] == np.float32(0.1)

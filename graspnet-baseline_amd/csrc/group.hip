@@ -64,14 +64,15 @@ __global__ __launch_bounds__(256) void group_points_grad_kernel(const float *__r
 // interpolate_gpu.cu:14-64: one lane per unknown point, serial ascending scan of `known`
 // (order-dependent strict '<' cascade, so the scan order is the reference's).
 // The known set is staged through LDS in tiles so each coordinate is read from HBM once per block.
-__global__ __launch_bounds__(256) void three_nn_kernel(const float *__restrict__ unknown,
+constexpr int NN_THREADS = 64;   // small blocks: the scan is a serial chain per lane, so spread lanes over many CUs
+__global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float *__restrict__ unknown,
                                                        const float *__restrict__ known, int n, int m,
                                                        float *__restrict__ dist2,
                                                        int32_t *__restrict__ idx) {
   constexpr int TILE = 1024;
   __shared__ float s_known[TILE * 3];
   const int b = blockIdx.y;
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int j = blockIdx.x * NN_THREADS + threadIdx.x;
   unknown += (size_t)b * n * 3;
   known += (size_t)b * m * 3;
   const bool live = j < n;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void three_nn_kernel(const float *__restrict__
   for (int k0 = 0; k0 < m; k0 += TILE) {
     const int cnt = min(TILE, m - k0);
     __syncthreads();
-    for (int i = threadIdx.x; i < cnt * 3; i += 256) s_known[i] = known[k0 * 3 + i];
+    for (int i = threadIdx.x; i < cnt * 3; i += NN_THREADS) s_known[i] = known[k0 * 3 + i];
     __syncthreads();
     for (int kk = 0; kk < cnt; ++kk) {
       const float x = s_known[kk * 3 + 0], y = s_known[kk * 3 + 1], z = s_known[kk * 3 + 2];
@@ -225,8 +226,8 @@ extern "C" int gn_three_nn(const float *unknown, const float *known, int b, int 
   GN_COMMON_CHECKS("three_nn", b >= 0 && n >= 0 && m >= 0);
   if (b == 0 || n == 0) return GN_OK;
   GN_REQUIRE(unknown && dist2 && idx && (known || m == 0), "three_nn: null pointer");
-  dim3 grid((n + 255) / 256, b);
-  hipLaunchKernelGGL(three_nn_kernel, grid, dim3(256), 0, as_stream(stream), unknown, known, n, m, dist2, idx);
+  dim3 grid((n + NN_THREADS - 1) / NN_THREADS, b);
+  hipLaunchKernelGGL(three_nn_kernel, grid, dim3(NN_THREADS), 0, as_stream(stream), unknown, known, n, m, dist2, idx);
   GN_CHECK_LAUNCH("three_nn");
   return GN_OK;
 }

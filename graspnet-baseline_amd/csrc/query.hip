@@ -14,30 +14,39 @@ namespace gn {
 
 constexpr int QUERY_WAVES = 4;  // waves (= centres in flight) per workgroup
 
-template <bool CYL>
+// NC centres per wave share every loaded 64-point chunk (the loads and address math are amortised;
+// most chunks contain no hit for a given centre, so the slot bookkeeping is rarely executed).
+template <bool CYL, int NC>
 __global__ __launch_bounds__(QUERY_WAVES * 64) void query_kernel(
     const float *__restrict__ new_xyz, const float *__restrict__ xyz, const float *__restrict__ rot,
     int n, int m, float radius, float hmin, float hmax, int nsample, int32_t *__restrict__ idx) {
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
-  const int j = blockIdx.x * QUERY_WAVES + (threadIdx.x >> 6);
-  if (j >= m) return;  // wave-uniform
+  const int j0 = (blockIdx.x * QUERY_WAVES + (threadIdx.x >> 6)) * NC;
+  if (j0 >= m) return;  // wave-uniform
   xyz += (size_t)b * n * 3;
-  const float *c = new_xyz + ((size_t)b * m + j) * 3;
-  int32_t *row = idx + ((size_t)b * m + j) * nsample;
-
   const float radius2 = radius * radius;  // ball_query_gpu.cu:27
-  const float cx = c[0], cy = c[1], cz = c[2];
-  float r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0, r8 = 0;
-  if (CYL) {
-    const float *r = rot + ((size_t)b * m + j) * 9;
-    r0 = r[0]; r1 = r[1]; r2 = r[2]; r3 = r[3]; r4 = r[4]; r5 = r[5]; r6 = r[6]; r7 = r[7]; r8 = r[8];
+  float cx[NC], cy[NC], cz[NC], r[NC][9];
+  int cnt[NC], first[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int j = min(j0 + c, m - 1);
+    const float *cp = new_xyz + ((size_t)b * m + j) * 3;
+    cx[c] = cp[0]; cy[c] = cp[1]; cz[c] = cp[2];
+    if (CYL) {
+      const float *rp = rot + ((size_t)b * m + j) * 9;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) r[c][q] = rp[q];
+    }
+    cnt[c] = (j0 + c < m) ? 0 : nsample;   // centres past the end are born finished
+    first[c] = 0;
   }
-
-  int cnt = 0;
-  int first = 0;
-  constexpr int U = 4;  // 64-point chunks per iteration: their loads are issued together (latency overlap)
-  for (int k0 = 0; k0 < n && cnt < nsample; k0 += 64 * U) {
+  constexpr int U = 2;  // 64-point chunks per iteration: their loads are issued together
+  for (int k0 = 0; k0 < n; k0 += 64 * U) {
+    bool done = true;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) done = done && cnt[c] >= nsample;
+    if (done) break;
     float px[U], py[U], pz[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -47,35 +56,44 @@ __global__ __launch_bounds__(QUERY_WAVES * 64) void query_kernel(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int k = k0 + u * 64 + lane;
-      bool hit;
-      if (CYL) {
-        // cylinder_query_gpu.cu:36-46
-        const float x = px[u] - cx, y = py[u] - cy, z = pz[u] - cz;
-        const float x_rot = r0 * x + r3 * y + r6 * z;
-        const float y_rot = r1 * x + r4 * y + r7 * z;
-        const float z_rot = r2 * x + r5 * y + r8 * z;
-        const float d2 = y_rot * y_rot + z_rot * z_rot;
-        hit = d2 < radius2 && x_rot > hmin && x_rot < hmax;
-      } else {
-        // ball_query_gpu.cu:33-38
-        const float d2 = (cx - px[u]) * (cx - px[u]) + (cy - py[u]) * (cy - py[u]) + (cz - pz[u]) * (cz - pz[u]);
-        hit = d2 < radius2;
-      }
-      hit = hit && k < n;
-      const unsigned long long mask = __ballot(hit);
-      if (mask && cnt < nsample) {
-        if (cnt == 0) first = k0 + u * 64 + __ffsll((long long)mask) - 1;
-        const int slot = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-        if (hit && slot < nsample) row[slot] = k;
-        cnt += __popcll(mask);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        bool hit;
+        if (CYL) {
+          // cylinder_query_gpu.cu:36-46
+          const float x = px[u] - cx[c], y = py[u] - cy[c], z = pz[u] - cz[c];
+          const float x_rot = r[c][0] * x + r[c][3] * y + r[c][6] * z;
+          const float y_rot = r[c][1] * x + r[c][4] * y + r[c][7] * z;
+          const float z_rot = r[c][2] * x + r[c][5] * y + r[c][8] * z;
+          const float d2 = y_rot * y_rot + z_rot * z_rot;
+          hit = d2 < radius2 && x_rot > hmin && x_rot < hmax;
+        } else {
+          // ball_query_gpu.cu:33-38
+          const float d2 = (cx[c] - px[u]) * (cx[c] - px[u]) + (cy[c] - py[u]) * (cy[c] - py[u]) +
+                           (cz[c] - pz[u]) * (cz[c] - pz[u]);
+          hit = d2 < radius2;
+        }
+        hit = hit && k < n;
+        const unsigned long long mask = __ballot(hit);
+        if (mask && cnt[c] < nsample) {
+          int32_t *row = idx + ((size_t)b * m + j0 + c) * nsample;
+          if (cnt[c] == 0) first[c] = k0 + u * 64 + __ffsll((long long)mask) - 1;
+          const int slot = cnt[c] + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+          if (hit && slot < nsample) row[slot] = k;
+          cnt[c] += __popcll(mask);
+        }
       }
     }
   }
   // unfilled slots repeat the first hit (ball_query_gpu.cu:39-43); no hit -> zeros
   // (the reference's torch::zeros output, ball_query.cpp:24-26)
-  if (cnt < nsample)
-    for (int l = cnt + lane; l < nsample; l += 64) row[l] = first;
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+    if (j0 + c < m && cnt[c] < nsample) {
+      int32_t *row = idx + ((size_t)b * m + j0 + c) * nsample;
+      for (int l = cnt[c] + lane; l < nsample; l += 64) row[l] = first[c];
+    }
 }
 
 // CloudCrop runs four cylinder queries that differ only in hmax (models/modules.py:103-106).
@@ -246,9 +264,17 @@ static int launch_query(const float *new_xyz, const float *xyz, const float *rot
   GN_REQUIRE(new_xyz && xyz && idx && (!CYL || rot), "%s: null pointer", name);
   GN_REQUIRE(b <= 65535, "%s: batch > 65535 unsupported", name);
   GN_REQUIRE((long)n * 3 < 0x7fffffffL, "%s: n too large", name);
-  dim3 grid((m + QUERY_WAVES - 1) / QUERY_WAVES, b);
-  hipLaunchKernelGGL((query_kernel<CYL>), grid, dim3(QUERY_WAVES * 64), 0, as_stream(stream), new_xyz,
-                     xyz, rot, n, m, radius, hmin, hmax, nsample, idx);
+  constexpr int NC = CYL ? 2 : 4;
+  // few centres (deep SA levels): one centre per wave keeps the chip busy
+  if ((long)b * m >= 8192) {
+    dim3 grid((m + QUERY_WAVES * NC - 1) / (QUERY_WAVES * NC), b);
+    hipLaunchKernelGGL((query_kernel<CYL, NC>), grid, dim3(QUERY_WAVES * 64), 0, as_stream(stream), new_xyz, xyz, rot,
+                       n, m, radius, hmin, hmax, nsample, idx);
+  } else {
+    dim3 grid((m + QUERY_WAVES - 1) / QUERY_WAVES, b);
+    hipLaunchKernelGGL((query_kernel<CYL, 1>), grid, dim3(QUERY_WAVES * 64), 0, as_stream(stream), new_xyz, xyz, rot, n,
+                       m, radius, hmin, hmax, nsample, idx);
+  }
   GN_CHECK_LAUNCH(name);
   return GN_OK;
 }

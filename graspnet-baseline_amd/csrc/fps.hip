@@ -23,6 +23,8 @@
 //
 // Distances are evaluated exactly as sampling_gpu.cu:108-109 writes them
 // (no FMA contraction; this file is compiled with -ffp-contract=off).
+#include <stdlib.h>
+
 #include "gn_common.h"
 
 namespace gn {
@@ -54,9 +56,11 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
                                                       int bs, int lg, int Q, unsigned qmagic,
                                                       int32_t *__restrict__ idx,
                                                       float *__restrict__ new_xyz) {
-  constexpr int NW = NT / 64;
-  __shared__ float s_val[2][16];
-  __shared__ int s_pos[2][16];
+  // cross-wave arg-max: every wave folds its candidate into ONE 64-bit LDS word with ds_max_u64,
+  //   key = (value bits << 32) | ~position     (values are >= 0 or the -1 sentinel mapped to 0)
+  // so the largest value wins and, among equal values, the lowest position = reference tie order.
+  // Three rotating words: word j%3 is used by iteration j and re-armed during iteration j+2.
+  __shared__ unsigned long long s_key[3];
 
   const int b = blockIdx.x;
   xyz += (size_t)b * n * 3;
@@ -64,7 +68,6 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
   if (new_xyz) new_xyz += (size_t)b * m * 3;
   const int t = threadIdx.x;
   const int lane = t & 63;
-  const int wave = t >> 6;
 
   float px[PPT], py[PPT], pz[PPT], tmp[PPT];
 #pragma unroll
@@ -88,6 +91,8 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
     idx[0] = 0;
     if (new_xyz) { new_xyz[0] = x1; new_xyz[1] = y1; new_xyz[2] = z1; }
   }
+  if (t < 3) s_key[t] = 0ULL;
+  __syncthreads();
 
   for (int j = 1; j < m; ++j) {
     float best = -1.0f;
@@ -103,30 +108,153 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
       bslot = gt ? s : bslot;
     }
     // ---- wave arg-max, lowest lane among equal maxima
-    const float wmax = wave_max(best);
+    const float rmax = row16_max_fast(best);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rmax), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rmax), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rmax), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rmax), 48));
+    const float wmax = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));   // scalar operands: folds to s/v ops, uniform
     const unsigned long long eq = __ballot(best == wmax);
     const int src = eq ? (__ffsll((long long)eq) - 1) : 0;
     const int wpos = __builtin_amdgcn_readlane(t * PPT + bslot, src);
-    const int buf = j & 1;
+    const int slot = j % 3;
     if (lane == 0) {
-      s_val[buf][wave] = wmax;
-      s_pos[buf][wave] = wpos;
+      // wmax < 0 only when every candidate of the wave is skipped/padding: key 0 loses to anything
+      const unsigned long long key =
+          wmax >= 0.0f ? (((unsigned long long)__float_as_uint(wmax) << 32) | (unsigned)(~wpos)) : 0ULL;
+      atomicMax(&s_key[slot], key);
+      if (t == 0) s_key[(j + 1) % 3] = 0ULL;   // last read in iteration j-2; every wave is past barrier j-1
     }
     __syncthreads();
-    // ---- across waves (every wave redoes the tiny reduction; lowest wave wins ties)
-    const float v = lane < NW ? s_val[buf][lane] : -2.0f;
-    const int pp = lane < NW ? s_pos[buf][lane] : 0;
-    const float gmax = __builtin_bit_cast(
-        float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row16_max(v))));
-    const unsigned long long eq2 = __ballot(v == gmax) & 0xFFFFull;
-    const int w = eq2 ? (__ffsll((long long)eq2) - 1) : 0;
-    const int gpos = __builtin_amdgcn_readlane(pp, w);
+    const unsigned long long gk = s_key[slot];
+    const unsigned ghi = __builtin_amdgcn_readfirstlane((unsigned)(gk >> 32));
+    const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gk);
     // all candidates skipped -> best=-1,besti=0 in every reference thread -> index 0
-    int k = gmax >= 0.0f ? pos_to_k(gpos, bs, lg, Q, qmagic, n) : 0;
+    int k = gk != 0ULL ? pos_to_k((int)~glo, bs, lg, Q, qmagic, n) : 0;
+    (void)ghi;
     k = __builtin_amdgcn_readfirstlane(k < 0 ? 0 : k);
     x1 = xyz[k * 3 + 0];
     y1 = xyz[k * 3 + 1];
     z1 = xyz[k * 3 + 2];
+    if (t == 0) {
+      idx[j] = k;
+      if (new_xyz) { new_xyz[j * 3 + 0] = x1; new_xyz[j * 3 + 1] = y1; new_xyz[j * 3 + 2] = z1; }
+    }
+  }
+}
+
+// Large clouds (24 576 < positions <= 65 536): the running min-distances still live in registers for
+// the whole chain (PPT per lane); the coordinates are tiered: RS slots per lane in registers, LS
+// slots in LDS (SoA [slot][thread], conflict-free), the rest streamed every iteration from a
+// rank-ordered SoA copy in the workspace (lane-consecutive addresses -> fully coalesced, L2-resident).
+// Thread t, slot s holds rank r = s*1024 + t, so a tie is resolved by the smallest r explicitly.
+template <int PPT, int RS, int LS>
+__global__ __launch_bounds__(1024) void fps_tier_kernel(const float *__restrict__ xyz, int n, int m, int bs, int lg,
+                                                        int Q, unsigned qmagic, float *__restrict__ ws,
+                                                        int32_t *__restrict__ idx, float *__restrict__ new_xyz) {
+  constexpr int NT = 1024, GS = PPT - RS - LS, CAP = NT * PPT;
+  static_assert(GS >= 0, "tiers exceed the slots");
+  extern __shared__ float s_xyz[];                 // [3][LS][NT]
+  __shared__ unsigned long long s_key[3];
+  const int b = blockIdx.x;
+  xyz += (size_t)b * n * 3;
+  idx += (size_t)b * m;
+  if (new_xyz) new_xyz += (size_t)b * m * 3;
+  // one buffer descriptor for this cloud's SoA copy; a slot is addressed as voffset = 4*t (one VGPR for
+  // every slot) + a compile-time scalar offset, so no per-slot address registers are kept live
+  float *gbase = ws + (size_t)b * 3 * CAP;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(gbase, 0, 3 * CAP * 4, 0x00020000);
+  const int t = threadIdx.x, lane = t & 63;
+  // streamed slots are stored in groups of 4 per lane ([array][group][thread][4]) and read back as one
+  // 16-byte buffer load per array and group
+  static_assert(GS % 4 == 0, "streamed slots come in groups of 4");
+  using f4 = __attribute__((ext_vector_type(4))) float;
+  const int voff16 = t * 16;
+
+  float rx[RS > 0 ? RS : 1], ry[RS > 0 ? RS : 1], rz[RS > 0 ? RS : 1], tmp[PPT];
+#pragma unroll
+  for (int s = 0; s < PPT; ++s) {
+    const int k = pos_to_k(s * NT + t, bs, lg, Q, qmagic, n);
+    float x = 0.f, y = 0.f, z = 0.f, t0 = -1.0f;
+    if (k >= 0) {
+      x = xyz[k * 3 + 0]; y = xyz[k * 3 + 1]; z = xyz[k * 3 + 2];
+      const float mag = (x * x) + (y * y) + (z * z);
+      t0 = ((double)mag <= 1e-3) ? -1.0f : 1e10f;
+    }
+    tmp[s] = t0;
+    if (s < RS) { rx[s] = x; ry[s] = y; rz[s] = z; }
+    else if (s < RS + LS) {
+      s_xyz[(0 * LS + (s - RS)) * NT + t] = x;
+      s_xyz[(1 * LS + (s - RS)) * NT + t] = y;
+      s_xyz[(2 * LS + (s - RS)) * NT + t] = z;
+    } else {
+      // each lane re-reads only its own entries
+      const int g = (s - RS - LS) >> 2, c = (s - RS - LS) & 3;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, x), rsrc, voff16 + c * 4, (0 * CAP + g * NT * 4) * 4, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, y), rsrc, voff16 + c * 4, (1 * CAP + g * NT * 4) * 4, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, z), rsrc, voff16 + c * 4, (2 * CAP + g * NT * 4) * 4, 0);
+    }
+  }
+  float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
+  if (t == 0) {
+    idx[0] = 0;
+    if (new_xyz) { new_xyz[0] = x1; new_xyz[1] = y1; new_xyz[2] = z1; }
+  }
+  if (t < 3) s_key[t] = 0ULL;
+  __syncthreads();
+
+  for (int j = 1; j < m; ++j) {
+    float best = -1.0f;
+    int bslot = 0;
+    f4 vx = {0.f, 0.f, 0.f, 0.f}, vy = vx, vz = vx;
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+      float x, y, z;
+      if (s < RS) { x = rx[s]; y = ry[s]; z = rz[s]; }
+      else if (s < RS + LS) {
+        x = s_xyz[(0 * LS + (s - RS)) * NT + t];
+        y = s_xyz[(1 * LS + (s - RS)) * NT + t];
+        z = s_xyz[(2 * LS + (s - RS)) * NT + t];
+      } else {
+        const int g = (s - RS - LS) >> 2, c = (s - RS - LS) & 3;
+        if (c == 0) {
+          vx = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff16, (0 * CAP + g * NT * 4) * 4, 0));
+          vy = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff16, (1 * CAP + g * NT * 4) * 4, 0));
+          vz = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff16, (2 * CAP + g * NT * 4) * 4, 0));
+        }
+        x = vx[c]; y = vy[c]; z = vz[c];
+      }
+      // bound the scheduler's load hoisting to one group: the loop is fully unrolled for static
+      // register indexing and would otherwise prefetch every slot and spill
+      if (s >= RS && ((s - RS) & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      const float dx = x - x1, dy = y - y1, dz = z - z1;
+      const float d = dx * dx + dy * dy + dz * dz;
+      const float d2 = vmin(d, tmp[s]);
+      tmp[s] = d2;
+      const bool gt = d2 > best;
+      best = gt ? d2 : best;
+      bslot = gt ? s : bslot;
+    }
+    const float rmax = row16_max_fast(best);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rmax), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rmax), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rmax), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rmax), 48));
+    const float wmax = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+    const int wrank = wave_min_i(best == wmax ? bslot * NT + t : 0x7fffffff);   // smallest rank among equal maxima
+    const int slot = j % 3;
+    if (lane == 0) {
+      const unsigned long long key =
+          wmax >= 0.0f ? (((unsigned long long)__float_as_uint(wmax) << 32) | (unsigned)(~wrank)) : 0ULL;
+      atomicMax(&s_key[slot], key);
+      if (t == 0) s_key[(j + 1) % 3] = 0ULL;
+    }
+    __syncthreads();
+    const unsigned long long gk = s_key[slot];
+    const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gk);
+    int k = gk != 0ULL ? pos_to_k((int)~glo, bs, lg, Q, qmagic, n) : 0;
+    k = __builtin_amdgcn_readfirstlane(k < 0 ? 0 : k);
+    x1 = xyz[k * 3 + 0]; y1 = xyz[k * 3 + 1]; z1 = xyz[k * 3 + 2];
     if (t == 0) {
       idx[j] = k;
       if (new_xyz) { new_xyz[j * 3 + 0] = x1; new_xyz[j * 3 + 1] = y1; new_xyz[j * 3 + 2] = z1; }
@@ -218,7 +346,9 @@ extern "C" size_t gn_fps_workspace_bytes(int b, int n) {
   if (b <= 0 || n <= 0) return 0;
   const int bs = gn::ref_block_size(n);
   const int Q = (n + bs - 1) / bs;
-  if ((long)bs * Q <= gn::kRegCapacity) return 0;
+  const long need = (long)bs * Q;
+  if (need <= gn::kRegCapacity) return 0;
+  if (need <= 1024L * 64) return (size_t)b * 3 * 1024 * 64 * sizeof(float);   // rank-ordered SoA copy (tier kernel)
   return (size_t)b * (size_t)n * sizeof(float);
 }
 
@@ -237,6 +367,7 @@ extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m,
   // ceil(2^32 / Q); exact floor-division for every position < 2^15 (register kernels hold <= 24576)
   const unsigned qmagic = Q == 1 ? 0xffffffffu : (unsigned)((0x100000000ull + Q - 1) / Q);
   hipStream_t s = as_stream(stream);
+  static const int variant = []() { const char *e = getenv("GN_FPS_VARIANT"); return e ? atoi(e) : 1; }();
 #define GN_FPS_LAUNCH(NT, PPT)                                                                    \
   hipLaunchKernelGGL((fps_reg_kernel<NT, PPT>), dim3(b), dim3(NT), 0, s, xyz, n, m, bs, lg, Q, qmagic, \
                      idx, new_xyz)
@@ -247,9 +378,29 @@ extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m,
   else if (need <= 1024 * 8) GN_FPS_LAUNCH(1024, 8);
   else if (need <= 1024 * 12) GN_FPS_LAUNCH(1024, 12);
   else if (need <= 1024 * 16) GN_FPS_LAUNCH(1024, 16);
+  else if (need <= 512 * 40 && variant == 1) GN_FPS_LAUNCH(512, 40);
+  else if (need <= 256 * 80 && variant == 2) GN_FPS_LAUNCH(256, 80);
   else if (need <= 1024 * 20) GN_FPS_LAUNCH(1024, 20);
   else if (need <= 1024 * 24) GN_FPS_LAUNCH(1024, 24);
-  else {
+  else if (need <= 1024L * 64) {
+    GN_REQUIRE(workspace != nullptr, "furthest_point_sampling: workspace required for n=%d", n);
+#define GN_FPS_TIER(PPT, RS, LS)                                                                          \
+  do {                                                                                                    \
+    auto kern = fps_tier_kernel<PPT, RS, LS>;                                                             \
+    const int lds = 3 * LS * 1024 * (int)sizeof(float);                                                   \
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            lds) != hipSuccess) {                                                         \
+      set_error("furthest_point_sampling: cannot reserve %d bytes of LDS", lds);                          \
+      return GN_ERR_LAUNCH;                                                                               \
+    }                                                                                                     \
+    hipLaunchKernelGGL(kern, dim3(b), dim3(1024), lds, s, xyz, n, m, bs, lg, Q, qmagic, (float *)workspace, idx, \
+                       new_xyz);                                                                          \
+  } while (0)
+    if (need <= 1024 * 32) GN_FPS_TIER(32, 15, 13);
+    else if (need <= 1024 * 49) GN_FPS_TIER(49, 8, 13);
+    else GN_FPS_TIER(64, 0, 12);
+#undef GN_FPS_TIER
+  } else {
     GN_REQUIRE(workspace != nullptr, "furthest_point_sampling: workspace required for n=%d", n);
     hipLaunchKernelGGL(fps_global_kernel, dim3(b), dim3(1024), 0, s, xyz, n, m, bs, lg, Q,
                        (float *)workspace, idx, new_xyz);

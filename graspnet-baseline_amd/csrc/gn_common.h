@@ -41,6 +41,24 @@ __device__ __forceinline__ int dpp_i(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 
+// max over each 16-lane row with the DPP fused into v_max_f32 (one instruction per step; hipcc's
+// fmaxf(v, dpp(v)) costs a v_mov_dpp plus two canonicalising v_max).  IEEE max: a NaN lane is
+// ignored, matching fmaxf.  s_nop 1 covers the VALU-write -> DPP-read hazard inside the statement.
+__device__ __forceinline__ float row16_max_fast(float v) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return v;
+}
+
 // max over each 16-lane row, result in every lane of the row
 __device__ __forceinline__ float row16_max(float v) {
   v = fmaxf(v, dpp_f<0xB1>(v));   // quad_perm [1,0,3,2]

@@ -34,10 +34,13 @@ def test_fps_bit_exact(E, oracle, n, m, variant):
     assert torch.equal(got, want)
 
 
-def test_fps_large_n_fallback(E, oracle):
-    x = _cloud(7, 1, 50000)
-    want = oracle.furthest_point_sampling(x, 256)
-    got = E.furthest_point_sampling(_dev(x), 256).cpu()
+@pytest.mark.parametrize("n,variant", [(50000, "uniform"), (30000, "surface"), (60000, "uniform"), (70000, "uniform")])
+def test_fps_large_n(E, oracle, n, variant):
+    """tiered kernel (temps in registers, coordinates in registers / LDS / L2) up to 65 536 positions,
+    any-n global-memory kernel beyond; duplicates in the surface variant force exact ties"""
+    x = _cloud(7, 2, n, variant)
+    want = oracle.furthest_point_sampling(x, 300)
+    got = E.furthest_point_sampling(_dev(x), 300).cpu()
     assert torch.equal(got, want)
 
 

@@ -143,6 +143,221 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Spatially-sorted variant for the model's main level (12 288 < positions <= 20 480; 24 points per
+// lane would spill past the 128 VGPRs a 1024-thread workgroup may use).
+//
+// Work per iteration is bound by VALU issue (4 waves per SIMD x PPT updates x ~12 instructions).
+// After a few dozen samples most of those updates are no-ops: a point's running distance can only
+// shrink if the new sample is closer than its current value.  Each of the 16 waves therefore owns
+// one spatial CELL of the cloud (4 x-slabs x 4 y-slabs of equal population, built in LDS with two
+// histogram / prefix / ticket passes), keeps its bounding box and its cached (max, candidate), and
+// SKIPS an iteration when  dist^2(new sample, box) * (1 - 1e-5)  >=  its cached max:
+// then min(d, temp) == temp for every point of the wave, exactly as the reference would compute.
+// The placement of points is arbitrary with respect to the reference's tie order, so ties are
+// resolved by the explicit rank  bitrev(k % bs) * Q + k / bs  (carried in the LDS atomic-max key
+// across waves; inside a wave a flagged tie takes a rare slow path that scans for the minimum rank).
+constexpr int FPS_BINS = 2048;
+
+// exclusive prefix sum of a[0..2047] in LDS by 1024 threads (2 elements each); scratch: 16 ints
+__device__ __forceinline__ void block_exclusive_scan_2048(int *a, int *scratch, int t) {
+  const int lane = t & 63, wave = t >> 6;
+  const int a0 = a[2 * t], a1 = a[2 * t + 1];
+  int incl = a0 + a1;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) scratch[wave] = incl;
+  __syncthreads();
+  int woff = 0;
+  for (int w = 0; w < wave; ++w) woff += scratch[w];
+  const int excl = woff + incl - (a0 + a1);
+  a[2 * t] = excl;
+  a[2 * t + 1] = excl + a0;
+  __syncthreads();
+}
+
+template <int PPT>
+__global__ __launch_bounds__(1024) void fps_spatial_kernel(const float *__restrict__ xyz, int n, int m, int bs,
+                                                           int lg, int Q, unsigned qmagic,
+                                                           int32_t *__restrict__ idx, float *__restrict__ new_xyz) {
+  constexpr int NT = 1024, NW = 16, CELL = 64 * PPT;
+  extern __shared__ int lds_i[];
+  int *perm = lds_i;                 // [NW*CELL] position -> original index (-1 = empty)
+  int *hx = perm + NW * CELL;        // [FPS_BINS]
+  int *hy = hx + FPS_BINS;           // [4][FPS_BINS]
+  int *scr = hy + 4 * FPS_BINS;      // [64]
+  __shared__ unsigned long long s_key[3];
+
+  const int b = blockIdx.x;
+  xyz += (size_t)b * n * 3;
+  idx += (size_t)b * m;
+  if (new_xyz) new_xyz += (size_t)b * m * 3;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int bmask = bs - 1;
+  auto rank_of = [&](int k) { return bitrev_bits(k & bmask, lg) * Q + (k >> lg); };
+
+  // ---- S1: x / y extent of the cloud
+  float xmn = INFINITY, xmx = -INFINITY, ymn = INFINITY, ymx = -INFINITY;
+  for (int i = 0; i < PPT; ++i) {
+    const int k = t + i * NT;
+    if (k < n) {
+      const float x = xyz[k * 3 + 0], y = xyz[k * 3 + 1];
+      xmn = fminf(xmn, x); xmx = fmaxf(xmx, x); ymn = fminf(ymn, y); ymx = fmaxf(ymx, y);
+    }
+  }
+  float *scrf = reinterpret_cast<float *>(scr);
+  {
+    const float a0 = -wave_max(-xmn), a1 = wave_max(xmx), a2 = -wave_max(-ymn), a3 = wave_max(ymx);
+    if (lane == 0) { scrf[wave * 4 + 0] = a0; scrf[wave * 4 + 1] = a1; scrf[wave * 4 + 2] = a2; scrf[wave * 4 + 3] = a3; }
+  }
+  for (int i = t; i < 5 * FPS_BINS; i += NT) hx[i] = 0;      // hx and hy are contiguous
+  for (int i = t; i < NW * CELL; i += NT) perm[i] = -1;
+  __syncthreads();
+  xmn = scrf[0]; xmx = scrf[1]; ymn = scrf[2]; ymx = scrf[3];
+  for (int w = 1; w < NW; ++w) {
+    xmn = fminf(xmn, scrf[w * 4 + 0]); xmx = fmaxf(xmx, scrf[w * 4 + 1]);
+    ymn = fminf(ymn, scrf[w * 4 + 2]); ymx = fmaxf(ymx, scrf[w * 4 + 3]);
+  }
+  __syncthreads();
+  const float sx = xmx > xmn ? (float)FPS_BINS / (xmx - xmn) : 0.f;
+  const float sy = ymx > ymn ? (float)FPS_BINS / (ymx - ymn) : 0.f;
+  auto binx = [&](float x) { return min(FPS_BINS - 1, max(0, (int)((x - xmn) * sx))); };
+  auto biny = [&](float y) { return min(FPS_BINS - 1, max(0, (int)((y - ymn) * sy))); };
+  const int T2 = (n + 15) / 16;      // points per cell (<= CELL because 16*CELL >= n)
+  const int T1 = 4 * T2;             // points per x slab
+
+  // ---- S2: x slabs of equal population (histogram -> prefix -> ticket)
+  for (int i = 0; i < PPT; ++i) {
+    const int k = t + i * NT;
+    if (k < n) atomicAdd(&hx[binx(xyz[k * 3 + 0])], 1);
+  }
+  __syncthreads();
+  block_exclusive_scan_2048(hx, scr, t);
+  unsigned long long slabs = 0ULL;     // 2 bits per owned point
+  for (int i = 0; i < PPT; ++i) {
+    const int k = t + i * NT;
+    if (k < n) {
+      const int q = atomicAdd(&hx[binx(xyz[k * 3 + 0])], 1);
+      const int sl = min(q / T1, 3);
+      slabs |= (unsigned long long)sl << (2 * i);
+      atomicAdd(&hy[sl * FPS_BINS + biny(xyz[k * 3 + 1])], 1);
+    }
+  }
+  __syncthreads();
+  // ---- S3: y cells inside each slab
+  for (int sl = 0; sl < 4; ++sl) block_exclusive_scan_2048(hy + sl * FPS_BINS, scr, t);
+  for (int i = 0; i < PPT; ++i) {
+    const int k = t + i * NT;
+    if (k < n) {
+      const int sl = (int)((slabs >> (2 * i)) & 3ULL);
+      const int q2 = atomicAdd(&hy[sl * FPS_BINS + biny(xyz[k * 3 + 1])], 1);
+      const int cy = min(q2 / T2, 3);
+      const int r = q2 - cy * T2;                     // < T2 <= CELL (last cell: slab population <= T1)
+      perm[(sl * 4 + cy) * CELL + min(r, CELL - 1)] = k;
+    }
+  }
+  __syncthreads();
+
+  // ---- load this lane's points: wave = cell, slot s of lane l = cell entry s*64 + l
+  float px[PPT], py[PPT], pz[PPT], tmp[PPT];
+  float bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY, bz0 = INFINITY, bz1 = -INFINITY;
+#pragma unroll
+  for (int s = 0; s < PPT; ++s) {
+    const int k = perm[wave * CELL + s * 64 + lane];
+    float x = 0.f, y = 0.f, z = 0.f, t0 = -1.0f;
+    if (k >= 0) {
+      x = xyz[k * 3 + 0]; y = xyz[k * 3 + 1]; z = xyz[k * 3 + 2];
+      const float mag = (x * x) + (y * y) + (z * z);
+      t0 = ((double)mag <= 1e-3) ? -1.0f : 1e10f;       // sampling_gpu.cu:105-106, sampling.cpp:78-80
+      bx0 = fminf(bx0, x); bx1 = fmaxf(bx1, x); by0 = fminf(by0, y); by1 = fmaxf(by1, y);
+      bz0 = fminf(bz0, z); bz1 = fmaxf(bz1, z);
+    }
+    px[s] = x; py[s] = y; pz[s] = z; tmp[s] = t0;
+  }
+  bx0 = -wave_max(-bx0); bx1 = wave_max(bx1); by0 = -wave_max(-by0); by1 = wave_max(by1);
+  bz0 = -wave_max(-bz0); bz1 = wave_max(bz1);
+
+  float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
+  if (t == 0) {
+    idx[0] = 0;
+    if (new_xyz) { new_xyz[0] = x1; new_xyz[1] = y1; new_xyz[2] = z1; }
+  }
+  if (t < 3) s_key[t] = 0ULL;
+  __syncthreads();
+
+  float c_wmax = INFINITY;            // cached max of this wave's running distances (inf = not computed yet)
+  unsigned long long c_key = 0ULL;
+  for (int j = 1; j < m; ++j) {
+    // distance^2 from the new sample to this wave's box (0 inside); empty wave: box is inverted -> inf
+    const float ex = fmaxf(fmaxf(bx0 - x1, x1 - bx1), 0.f);
+    const float ey = fmaxf(fmaxf(by0 - y1, y1 - by1), 0.f);
+    const float ez = fmaxf(fmaxf(bz0 - z1, z1 - bz1), 0.f);
+    const float lb = (ex * ex + ey * ey + ez * ez) * 0.99999f;
+    if (!(lb >= c_wmax)) {            // wave-uniform
+      float best = -1.0f;
+      int bslot = 0;
+      bool tie = false;
+#pragma unroll
+      for (int s = 0; s < PPT; ++s) {
+        const float dx = px[s] - x1, dy = py[s] - y1, dz = pz[s] - z1;
+        const float d = dx * dx + dy * dy + dz * dz;
+        const float d2 = vmin(d, tmp[s]);
+        tmp[s] = d2;
+        tie = tie || (d2 == best);
+        const bool gt = d2 > best;
+        best = gt ? d2 : best;
+        bslot = gt ? s : bslot;
+      }
+      const float rmax = row16_max_fast(best);
+      const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rmax), 0));
+      const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rmax), 16));
+      const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rmax), 32));
+      const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rmax), 48));
+      const float wmax = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+      const bool mine = best == wmax;
+      const unsigned long long eq = __ballot(mine);
+      int wrank;
+      if (wmax < 0.0f) {
+        wrank = 0;
+      } else if (__popcll(eq) > 1 || __ballot(mine && tie)) {
+        // rare: several points of the wave share the maximum -> reference order = smallest rank
+        int myr = 0x7fffffff;
+#pragma unroll
+        for (int s = 0; s < PPT; ++s)
+          if (tmp[s] == wmax) {
+            const int k = perm[wave * CELL + s * 64 + lane];
+            if (k >= 0) myr = min(myr, rank_of(k));
+          }
+        wrank = wave_min_i(myr);
+      } else {
+        const int src = __ffsll((long long)eq) - 1;
+        const int kc = perm[wave * CELL + bslot * 64 + lane];
+        wrank = rank_of(__builtin_amdgcn_readlane(kc, src));
+      }
+      c_wmax = wmax;
+      c_key = wmax >= 0.0f ? (((unsigned long long)__float_as_uint(wmax) << 32) | (unsigned)(~wrank)) : 0ULL;
+    }
+    const int slot = j % 3;
+    if (lane == 0) {
+      atomicMax(&s_key[slot], c_key);
+      if (t == 0) s_key[(j + 1) % 3] = 0ULL;
+    }
+    __syncthreads();
+    const unsigned long long gk = s_key[slot];
+    const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gk);
+    int k = gk != 0ULL ? pos_to_k((int)~glo, bs, lg, Q, qmagic, n) : 0;   // rank -> index
+    k = __builtin_amdgcn_readfirstlane(k < 0 ? 0 : k);
+    x1 = xyz[k * 3 + 0]; y1 = xyz[k * 3 + 1]; z1 = xyz[k * 3 + 2];
+    if (t == 0) {
+      idx[j] = k;
+      if (new_xyz) { new_xyz[j * 3 + 0] = x1; new_xyz[j * 3 + 1] = y1; new_xyz[j * 3 + 2] = z1; }
+    }
+  }
+}
+
 // Large clouds (24 576 < positions <= 65 536): the running min-distances still live in registers for
 // the whole chain (PPT per lane); the coordinates are tiered: RS slots per lane in registers, LS
 // slots in LDS (SoA [slot][thread], conflict-free), the rest streamed every iteration from a
@@ -367,7 +582,7 @@ extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m,
   // ceil(2^32 / Q); exact floor-division for every position < 2^15 (register kernels hold <= 24576)
   const unsigned qmagic = Q == 1 ? 0xffffffffu : (unsigned)((0x100000000ull + Q - 1) / Q);
   hipStream_t s = as_stream(stream);
-  static const int variant = []() { const char *e = getenv("GN_FPS_VARIANT"); return e ? atoi(e) : 1; }();
+  static const int variant = []() { const char *e = getenv("GN_FPS_VARIANT"); return e ? atoi(e) : 3; }();
 #define GN_FPS_LAUNCH(NT, PPT)                                                                    \
   hipLaunchKernelGGL((fps_reg_kernel<NT, PPT>), dim3(b), dim3(NT), 0, s, xyz, n, m, bs, lg, Q, qmagic, \
                      idx, new_xyz)
@@ -378,6 +593,19 @@ extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m,
   else if (need <= 1024 * 8) GN_FPS_LAUNCH(1024, 8);
   else if (need <= 1024 * 12) GN_FPS_LAUNCH(1024, 12);
   else if (need <= 1024 * 16) GN_FPS_LAUNCH(1024, 16);
+#define GN_FPS_SPATIAL(PPT)                                                                                 \
+  do {                                                                                                      \
+    auto kern = fps_spatial_kernel<PPT>;                                                                    \
+    const int lds = (16 * 64 * PPT + 5 * FPS_BINS + 64) * (int)sizeof(int);                                 \
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            lds) != hipSuccess) {                                                           \
+      set_error("furthest_point_sampling: cannot reserve %d bytes of LDS", lds);                            \
+      return GN_ERR_LAUNCH;                                                                                 \
+    }                                                                                                       \
+    hipLaunchKernelGGL(kern, dim3(b), dim3(1024), lds, s, xyz, n, m, bs, lg, Q, qmagic, idx, new_xyz);      \
+  } while (0)
+  else if (need > 1024 * 12 && need <= 1024 * 16 && variant == 3) GN_FPS_SPATIAL(16);
+  else if (need > 1024 * 16 && need <= 1024 * 20 && variant == 3) GN_FPS_SPATIAL(20);
   else if (need <= 512 * 40 && variant == 1) GN_FPS_LAUNCH(512, 40);
   else if (need <= 256 * 80 && variant == 2) GN_FPS_LAUNCH(256, 80);
   else if (need <= 1024 * 20) GN_FPS_LAUNCH(1024, 20);

@@ -26,7 +26,9 @@ def _dev(t):
 @pytest.mark.parametrize("n,m,variant", [(20000, 2048, "uniform"), (20000, 2048, "surface"), (2048, 1024, "uniform"),
                                          (1024, 512, "uniform"), (512, 256, "uniform"), (300, 128, "uniform"),
                                          (77, 77, "uniform"), (5000, 700, "surface"), (9000, 64, "uniform"),
-                                         (13000, 64, "uniform"), (17000, 64, "uniform"), (24000, 64, "uniform")])
+                                         (13000, 64, "uniform"), (17000, 64, "uniform"), (24000, 64, "uniform"),
+                                         (13000, 900, "surface"), (16384, 2048, "surface"), (20480, 1500, "uniform"),
+                                         (12289, 300, "surface")])
 def test_fps_bit_exact(E, oracle, n, m, variant):
     x = _cloud(100 + n, 2, n, variant)
     want = oracle.furthest_point_sampling(x, m)

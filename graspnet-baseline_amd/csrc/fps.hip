@@ -55,7 +55,18 @@ template <int NT, int PPT>
 __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ xyz, int n, int m,
                                                       int bs, int lg, int Q, unsigned qmagic,
                                                       int32_t *__restrict__ idx,
-                                                      float *__restrict__ new_xyz) {
+                                                      float *__restrict__ new_xyz,
+                                                      const int32_t *__restrict__ prefix_ok) {
+  // `xyz` is the FPS order of a superset whose sampling met no exact tie between distinct points
+  // during its first prefix_ok[b] iterations (written by the producing call's tie_out): if that
+  // covers the m samples wanted here, the result is provably the identity prefix.
+  if (prefix_ok && prefix_ok[blockIdx.x] >= m && m <= n) {
+    const float *src = xyz + (size_t)blockIdx.x * n * 3;
+    for (int j = threadIdx.x; j < m; j += NT) idx[(size_t)blockIdx.x * m + j] = j;
+    if (new_xyz)
+      for (int e = threadIdx.x; e < m * 3; e += NT) new_xyz[(size_t)blockIdx.x * m * 3 + e] = src[e];
+    return;
+  }
   // cross-wave arg-max: every wave folds its candidate into ONE 64-bit LDS word with ds_max_u64,
   //   key = (value bits << 32) | ~position     (values are >= 0 or the -1 sentinel mapped to 0)
   // so the largest value wins and, among equal values, the lowest position = reference tie order.
@@ -182,7 +193,8 @@ __device__ __forceinline__ void block_exclusive_scan_2048(int *a, int *scratch, 
 template <int PPT>
 __global__ __launch_bounds__(1024) void fps_spatial_kernel(const float *__restrict__ xyz, int n, int m, int bs,
                                                            int lg, int Q, unsigned qmagic,
-                                                           int32_t *__restrict__ idx, float *__restrict__ new_xyz) {
+                                                           int32_t *__restrict__ idx, float *__restrict__ new_xyz,
+                                                           int32_t *__restrict__ tie_out) {
   constexpr int NT = 1024, NW = 16, CELL = 64 * PPT;
   extern __shared__ int lds_i[];
   int *perm = lds_i;                 // [NW*CELL] position -> original index (-1 = empty)
@@ -290,6 +302,8 @@ __global__ __launch_bounds__(1024) void fps_spatial_kernel(const float *__restri
 
   float c_wmax = INFINITY;            // cached max of this wave's running distances (inf = not computed yet)
   unsigned long long c_key = 0ULL;
+  bool c_tie = false;                 // the cached max is shared by points with DIFFERENT coordinates
+  int first_tie = 0x7fffffff;         // first iteration whose global max was such a tie (or had no candidate)
   for (int j = 1; j < m; ++j) {
     // distance^2 from the new sample to this wave's box (0 inside); empty wave: box is inverted -> inf
     const float ex = fmaxf(fmaxf(bx0 - x1, x1 - bx1), 0.f);
@@ -320,18 +334,28 @@ __global__ __launch_bounds__(1024) void fps_spatial_kernel(const float *__restri
       const bool mine = best == wmax;
       const unsigned long long eq = __ballot(mine);
       int wrank;
+      c_tie = false;
       if (wmax < 0.0f) {
         wrank = 0;
       } else if (__popcll(eq) > 1 || __ballot(mine && tie)) {
-        // rare: several points of the wave share the maximum -> reference order = smallest rank
+        // rare: several points of the wave share the maximum -> reference order = smallest rank.
+        // Exact duplicates of one location are harmless for the prefix property (the loser drops to
+        // distance 0 and is never sampled); a tie between different locations is recorded.
         int myr = 0x7fffffff;
+        float lx0 = INFINITY, lx1 = -INFINITY, ly0 = INFINITY, ly1 = -INFINITY, lz0 = INFINITY, lz1 = -INFINITY;
 #pragma unroll
         for (int s = 0; s < PPT; ++s)
           if (tmp[s] == wmax) {
             const int k = perm[wave * CELL + s * 64 + lane];
-            if (k >= 0) myr = min(myr, rank_of(k));
+            if (k >= 0) {
+              myr = min(myr, rank_of(k));
+              lx0 = fminf(lx0, px[s]); lx1 = fmaxf(lx1, px[s]); ly0 = fminf(ly0, py[s]); ly1 = fmaxf(ly1, py[s]);
+              lz0 = fminf(lz0, pz[s]); lz1 = fmaxf(lz1, pz[s]);
+            }
           }
         wrank = wave_min_i(myr);
+        c_tie = (-wave_max(-lx0) != wave_max(lx1)) || (-wave_max(-ly0) != wave_max(ly1)) ||
+                (-wave_max(-lz0) != wave_max(lz1));
       } else {
         const int src = __ffsll((long long)eq) - 1;
         const int kc = perm[wave * CELL + bslot * 64 + lane];
@@ -348,6 +372,9 @@ __global__ __launch_bounds__(1024) void fps_spatial_kernel(const float *__restri
     __syncthreads();
     const unsigned long long gk = s_key[slot];
     const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gk);
+    // this wave holds the global maximum value: a tie if it is not the (unique) winner or ties inside
+    if (gk == 0ULL || ((unsigned)(c_key >> 32) == (unsigned)(gk >> 32) && c_key != 0ULL && (c_tie || c_key != gk)))
+      first_tie = min(first_tie, j);
     int k = gk != 0ULL ? pos_to_k((int)~glo, bs, lg, Q, qmagic, n) : 0;   // rank -> index
     k = __builtin_amdgcn_readfirstlane(k < 0 ? 0 : k);
     x1 = xyz[k * 3 + 0]; y1 = xyz[k * 3 + 1]; z1 = xyz[k * 3 + 2];
@@ -355,6 +382,15 @@ __global__ __launch_bounds__(1024) void fps_spatial_kernel(const float *__restri
       idx[j] = k;
       if (new_xyz) { new_xyz[j * 3 + 0] = x1; new_xyz[j * 3 + 1] = y1; new_xyz[j * 3 + 2] = z1; }
     }
+  }
+  if (tie_out) {
+    // a cross-wave tie is seen by the losing wave(s) only: combine over the workgroup
+    __shared__ int s_tie;
+    if (t == 0) s_tie = 0x7fffffff;
+    __syncthreads();
+    if (lane == 0) atomicMin(&s_tie, first_tie);
+    __syncthreads();
+    if (t == 0) tie_out[b] = s_tie;
   }
 }
 
@@ -568,7 +604,8 @@ extern "C" size_t gn_fps_workspace_bytes(int b, int n) {
 }
 
 extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m, void *workspace,
-                                          int32_t *idx, float *new_xyz, gn_stream_t stream) {
+                                          int32_t *idx, float *new_xyz, int32_t *tie_out,
+                                          const int32_t *prefix_ok, gn_stream_t stream) {
   using namespace gn;
   GN_REQUIRE(b >= 0 && n >= 1 && m >= 0, "furthest_point_sampling: bad sizes b=%d n=%d m=%d", b, n, m);
   if (b == 0 || m == 0) return GN_OK;
@@ -582,10 +619,11 @@ extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m,
   // ceil(2^32 / Q); exact floor-division for every position < 2^15 (register kernels hold <= 24576)
   const unsigned qmagic = Q == 1 ? 0xffffffffu : (unsigned)((0x100000000ull + Q - 1) / Q);
   hipStream_t s = as_stream(stream);
+  bool tie_written = false;
   static const int variant = []() { const char *e = getenv("GN_FPS_VARIANT"); return e ? atoi(e) : 3; }();
 #define GN_FPS_LAUNCH(NT, PPT)                                                                    \
   hipLaunchKernelGGL((fps_reg_kernel<NT, PPT>), dim3(b), dim3(NT), 0, s, xyz, n, m, bs, lg, Q, qmagic, \
-                     idx, new_xyz)
+                     idx, new_xyz, prefix_ok)
   if (need <= 256 * 2) GN_FPS_LAUNCH(256, 2);
   else if (need <= 256 * 4) GN_FPS_LAUNCH(256, 4);
   else if (need <= 1024 * 2) GN_FPS_LAUNCH(1024, 2);
@@ -602,7 +640,9 @@ extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m,
       set_error("furthest_point_sampling: cannot reserve %d bytes of LDS", lds);                            \
       return GN_ERR_LAUNCH;                                                                                 \
     }                                                                                                       \
-    hipLaunchKernelGGL(kern, dim3(b), dim3(1024), lds, s, xyz, n, m, bs, lg, Q, qmagic, idx, new_xyz);      \
+    hipLaunchKernelGGL(kern, dim3(b), dim3(1024), lds, s, xyz, n, m, bs, lg, Q, qmagic, idx, new_xyz,      \
+                       tie_out);                                                                            \
+    tie_written = true;                                                                                     \
   } while (0)
   else if (need > 1024 * 12 && need <= 1024 * 16 && variant == 3) GN_FPS_SPATIAL(16);
   else if (need > 1024 * 16 && need <= 1024 * 20 && variant == 3) GN_FPS_SPATIAL(20);
@@ -634,6 +674,11 @@ extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m,
                        (float *)workspace, idx, new_xyz);
   }
 #undef GN_FPS_LAUNCH
+  // kernels without tie tracking report "unknown" = a tie at step 0
+  if (tie_out && !tie_written && hipMemsetAsync(tie_out, 0, sizeof(int32_t) * (size_t)b, s) != hipSuccess) {
+    set_error("furthest_point_sampling: memset failed");
+    return GN_ERR_LAUNCH;
+  }
   GN_CHECK_LAUNCH("furthest_point_sampling");
   return GN_OK;
 }

@@ -22,7 +22,8 @@ SIGNATURES = {
     "gn_last_error": (ctypes.c_char_p, []),
     "gn_version": (ctypes.c_char_p, []),
     "gn_fps_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
-    "gn_furthest_point_sampling": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "gn_furthest_point_sampling": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                           _c_void_p, _c_void_p]),
     "gn_gather_points": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
     "gn_gather_points_grad": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
     "gn_ball_query": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_int, _c_void_p, _c_void_p]),

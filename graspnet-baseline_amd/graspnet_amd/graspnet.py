@@ -134,13 +134,17 @@ class GraspNet:
             # ---- 4 set-abstraction levels (backbone.py:105-121)
             lv_xyz, lv_feat, lv_n, lv_inds = xyz, None, N, []
             feats = []
+            # SA1's sampler reports whether any arg-max was an exact tie between distinct points; if not, the
+            # deeper levels' samplers (which run on FPS-ordered input) are the identity prefix and say so at once
+            tie_flag = torch.empty((B,), dtype=i32, device=dev)
             for li, (npoint, radius, nsample, c, mlp) in enumerate(SA_CFG):
                 inds = torch.empty((B, npoint), dtype=i32, device=dev)
                 new_xyz = torch.empty((B, npoint, 3), dtype=f32, device=dev)
                 wsb = lib.gn_fps_workspace_bytes(B, lv_n)
                 ws = torch.empty((wsb,), dtype=torch.uint8, device=dev) if wsb else None
                 self._run("furthest_point_sampling[%d]" % (li + 1), lambda: lib.gn_furthest_point_sampling(lv_xyz.data_ptr(), B, lv_n, npoint, L.ptr(ws), inds.data_ptr(),
-                                                       new_xyz.data_ptr(), st))
+                                                       new_xyz.data_ptr(), tie_flag.data_ptr() if li == 0 else None,
+                                                       tie_flag.data_ptr() if li > 0 else None, st))
                 idx = torch.empty((B, npoint, nsample), dtype=i32, device=dev)
                 self._run("ball_query[%d]" % (li + 1), lambda: lib.gn_ball_query(new_xyz.data_ptr(), lv_xyz.data_ptr(), B, lv_n, npoint, radius, nsample,
                                           idx.data_ptr(), st))

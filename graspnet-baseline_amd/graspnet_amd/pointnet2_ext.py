@@ -55,7 +55,7 @@ def furthest_point_sampling(points, nsamples):
     ws = torch.empty((wsb,), dtype=torch.uint8, device=points.device) if wsb else None
     with torch.cuda.device(points.device):
         L.check(lib.gn_furthest_point_sampling(points.data_ptr(), b, n, int(nsamples), L.ptr(ws),
-                                               out.data_ptr(), None, st), "furthest_point_sampling")
+                                               out.data_ptr(), None, None, None, st), "furthest_point_sampling")
     return out
 
 

@@ -58,10 +58,18 @@ const char *gn_version(void);
  * opt_n_threads(N).  `workspace` must hold gn_fps_workspace_bytes(B,N) bytes
  * (the reference's `temp` scratch, sampling.cpp:78-80); it may be NULL when
  * that function returns 0.  new_xyz (B,M,3) is optional (NULL to skip): the
- * sampled coordinates, i.e. gather_points() fused in. */
+ * sampled coordinates, i.e. gather_points() fused in.
+ * Optional, for the fused path (NULL otherwise):
+ *   tie_out (B) i32   : the first iteration whose maximum was shared by points at different
+ *                       locations (INT_MAX if none, 0 if the kernel variant does not track it);
+ *   prefix_ok (B) i32 : caller's promise that `xyz` is the FPS order produced by a call whose
+ *                       tie_out was prefix_ok: where prefix_ok[b] >= M the result is the identity
+ *                       prefix (provably what the full computation returns,
+ *                       models/backbone.py:110-119) and is written directly. */
 size_t gn_fps_workspace_bytes(int b, int n);
 int gn_furthest_point_sampling(const float *xyz, int b, int n, int m, void *workspace,
-                               int32_t *idx, float *new_xyz, gn_stream_t stream);
+                               int32_t *idx, float *new_xyz, int32_t *tie_out, const int32_t *prefix_ok,
+                               gn_stream_t stream);
 
 /* gather_points(points (B,C,N) f32, idx (B,M) i32) -> (B,C,M)   sampling.cpp:20-42 */
 int gn_gather_points(const float *points, const int32_t *idx, int b, int c, int n, int m,

@@ -294,6 +294,27 @@ def test_against_golden_samples(hip, golden_dir):
         assert abs(preds[i].shape[0] - g["model/pred/%d" % i].shape[0]) <= 4
 
 
+def test_fps_prefix_shortcut_and_tie_fallback(net, oracle):
+    """SA2-4 samplers short-circuit to the identity prefix only when SA1 met no tie between distinct points.
+    A lattice cloud is full of exact ties (flag set -> the deeper levels really run); a jittered one has none."""
+    g = torch.linspace(-0.25, 0.25, 26)
+    lat = torch.stack(torch.meshgrid(g, g, g + 0.65, indexing="ij"), -1).reshape(1, -1, 3).contiguous()   # 17576 points
+    jit = lat + torch.from_numpy(np.random.default_rng(5).normal(0, 1e-3, lat.shape).astype(np.float32))
+    for cloud, expect_tie in ((lat, True), (jit, False)):
+        ep = net({"point_clouds": cloud.cuda()})
+        want1 = oracle.furthest_point_sampling(cloud, 2048)
+        assert torch.equal(ep["sa1_inds"].cpu(), want1)
+        sa1_xyz = torch.gather(cloud, 1, want1.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        want2 = oracle.furthest_point_sampling(sa1_xyz, 1024)
+        assert torch.equal(ep["sa2_inds"].cpu(), want2)
+        assert torch.equal(ep["sa2_xyz"].cpu(), torch.gather(sa1_xyz, 1, want2.long().unsqueeze(-1).expand(-1, -1, 3)))
+        sa3 = oracle.furthest_point_sampling(ep["sa2_xyz"].cpu(), 512)
+        assert torch.equal(ep["sa3_xyz"].cpu(), torch.gather(ep["sa2_xyz"].cpu(), 1, sa3.long().unsqueeze(-1).expand(-1, -1, 3)))
+        identity = torch.equal(want2[0], torch.arange(1024, dtype=torch.int32))
+        if not expect_tie:
+            assert identity
+
+
 def test_refuses_cpu_and_training(state_dict):
     from graspnet_amd import GraspNet
     with pytest.raises(NotImplementedError):

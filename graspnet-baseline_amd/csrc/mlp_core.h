@@ -239,6 +239,40 @@ __device__ __forceinline__ void run_layer(const LayerW<CINP, COUTP> &w, const fl
   }
 }
 
+// ---- like run_layer, but the accumulators start from an LDS tile C0[TP][cstride] instead of the
+// bias (the hoisted, per-point part of a layer), and the result may overwrite that tile in place
+// (each 32x32 tile is read and written by the same wave only).
+template <int TP, int CINP, int COUTP, class Epi>
+__device__ __forceinline__ void run_layer_cinit(const LayerW<CINP, COUTP> &w, const float *__restrict__ xs,
+                                                const float *__restrict__ c0, int cstride, int wave, int lane,
+                                                Epi &epi, int mt_count = TP / 32) {
+  using LW = LayerW<CINP, COUTP>;
+  constexpr int XS = lds_stride(CINP);
+  const int wm = wave / LW::WN;
+  const int wn = wave % LW::WN;
+  for (int mt = wm; mt < mt_count; mt += LW::WM) {
+    f32x16 acc[LW::NTW];
+#pragma unroll
+    for (int i = 0; i < LW::NTW; ++i) {
+      const int col = (wn * LW::NTW + i) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = c0[(mt * 32 + acc_row(r, lane)) * cstride + col];
+    }
+    const float *xr = xs + (mt * 32 + (lane & 31)) * XS + 4 * (lane >> 5);
+#pragma unroll
+    for (int kb = 0; kb < LW::KB; ++kb) {
+      const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + kb * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < LW::NTW; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w.b[i][kb][s], acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < LW::NTW; ++i) epi(mt, wn * LW::NTW + i, i, acc[i]);
+  }
+}
+
 // ---- one layer, weights streamed from L2 in K chunks (for layers too wide to keep resident) ---
 // accumulators for all of this wave's tiles persist across the K chunks.
 template <int TP, int CINP, int COUTP, int KC, class Epi, int XS = lds_stride(CINP)>

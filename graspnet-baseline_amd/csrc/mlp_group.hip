@@ -170,6 +170,104 @@ __global__ __launch_bounds__(MLP_THREADS, MINW) void crop_mlp_kernel(const float
   }
 }
 
+// ---- set abstraction with layer 1 hoisted (levels with input features) ---------------------------
+// Layer 1 of a grouped MLP is  W1f * feat_j + W1x * (x_j - c_i)/r + b.  The first term does not depend
+// on the group, yet the reference (and sa_mlp_kernel) recompute it for each of the ~16 groups a
+// point belongs to.  gn_point_linear evaluates P_j = W1f * feat_j + b once per point; here the
+// gathered P rows initialise the accumulators and only the K=8 coordinate block is multiplied per
+// neighbour.  The k order (features, then coordinates) is the one sa_mlp_kernel uses, so results are
+// bit-identical to it.  The next tile's P rows (16 float4 per lane) and coordinate rows are fetched
+// into registers while the current tile runs layers 2-3.
+template <int C1, int C2, int C3, int NS>
+__global__ __launch_bounds__(MLP_THREADS) void sa_hoist_kernel(const float *__restrict__ xyz, int n,
+                                                               const float *__restrict__ pfeat,
+                                                               const float *__restrict__ new_xyz,
+                                                               const int32_t *__restrict__ idx, int np, int ntiles,
+                                                               int tpb, float radius, Mlp3Weights W,
+                                                               float *__restrict__ out) {
+  constexpr int TP = 128, GPT = TP / NS, XS0 = lds_stride(8), PS = lds_stride(C1), Q = C1 / 4;
+  constexpr int PF = TP * Q / MLP_THREADS;   // float4 of P per lane per tile
+  static_assert(TP * Q % MLP_THREADS == 0 && MLP_THREADS % Q == 0, "prefetch mapping");
+  constexpr int RSTEP = MLP_THREADS / Q;     // rows between a lane's consecutive float4
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *bufP = smem;                        // [TP][C1+4]  P rows, then layer-1 output in place
+  float *bufY2 = bufP + TP * PS;             // [TP][C2+4]
+  float *bufX = bufY2 + TP * lds_stride(C2); // 2 x [TP][12]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int prow = tid / Q, pc4 = tid % Q;
+
+  LayerW<8, C1> w1;
+  LayerW<C1, C2> w2;
+  LayerW<C2, C3> w3;
+  w1.load(W.w1, W.b1, wave, lane);
+  w2.load(W.w2, W.b2, wave, lane);
+  w3.load(W.w3, W.b3, wave, lane);
+
+  const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * tpb);
+  int tile = blockIdx.x * tpb;
+  if (tile >= tile_end) return;
+
+  auto fetch_p = [&](int tl, f32x4 (&pf)[PF]) {
+    const int g0 = tl * GPT;
+    const int b = g0 / np;
+    const int32_t *ix = idx + (size_t)g0 * NS;
+    const float *pb = pfeat + (size_t)b * n * C1 + pc4 * 4;
+#pragma unroll
+    for (int q = 0; q < PF; ++q) pf[q] = *reinterpret_cast<const f32x4 *>(pb + (size_t)ix[prow + q * RSTEP] * C1);
+  };
+  auto fetch_x = [&](int tl, f32x4 &v) {
+    const int g0 = tl * GPT;
+    const int b = g0 / np;
+    v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < TP) {
+      const int src = idx[(size_t)g0 * NS + tid];
+      const float *c = new_xyz + ((size_t)g0 + tid / NS) * 3;
+      const float *px = xyz + (size_t)b * n * 3;
+      v[0] = (px[src * 3 + 0] - c[0]) / radius;   // pointnet2_utils.py:346-348
+      v[1] = (px[src * 3 + 1] - c[1]) / radius;
+      v[2] = (px[src * 3 + 2] - c[2]) / radius;
+    }
+  };
+  auto put_p = [&](const f32x4 (&pf)[PF]) {
+#pragma unroll
+    for (int q = 0; q < PF; ++q) *reinterpret_cast<f32x4 *>(bufP + (prow + q * RSTEP) * PS + pc4 * 4) = pf[q];
+  };
+  auto put_x = [&](int buf, const f32x4 &v) {
+    if (tid < TP) {
+      float *x = bufX + buf * TP * XS0 + tid * XS0;
+      *reinterpret_cast<f32x4 *>(x) = v;
+      *reinterpret_cast<f32x4 *>(x + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  int buf = 0;
+  {
+    f32x4 pf[PF], v;
+    fetch_p(tile, pf);
+    fetch_x(tile, v);
+    put_p(pf);
+    put_x(0, v);
+  }
+  __syncthreads();
+  for (; tile < tile_end; ++tile) {
+    const int g0 = tile * GPT;
+    const bool has_next = tile + 1 < tile_end;
+    StoreLds<true> e1{bufP, PS, C1, lane};
+    run_layer_cinit<TP, 8, C1>(w1, bufX + buf * TP * XS0, bufP, PS, wave, lane, e1);
+    __syncthreads();
+    f32x4 pf[PF], nv;
+    if (has_next) { fetch_p(tile + 1, pf); fetch_x(tile + 1, nv); }   // in flight under layers 2-3
+    StoreLds<true> e2{bufY2, lds_stride(C2), C2, lane};
+    run_layer<TP, C1, C2>(w2, bufP, wave, lane, e2);
+    __syncthreads();
+    PoolGlobal<NS, LayerW<C2, C3>::NTW> e3{out + (size_t)g0 * C3, C3, lane, {}};
+    run_layer<TP, C2, C3>(w3, bufY2, wave, lane, e3);
+    if (has_next) { put_p(pf); put_x(buf ^ 1, nv); }   // bufP is free: every wave is past layer 2
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
 // ---- cloud crop over the UNIQUE rows of each seed (gn_cylinder_query_unique) ----------------------
 // One seed = one ragged row set (<= ND*NS entries, typically ~90): rows are evaluated once and
 // max-pooled into the depths named by their mask.  2.3-2.5x fewer MFMAs than pooling ND full lists,
@@ -409,5 +507,43 @@ extern "C" int gn_crop_unique_mlp_pool(const float *xyz, const float *seed_xyz, 
   hipLaunchKernelGGL(k, dim3((nseeds + spb - 1) / spb), dim3(MLP_THREADS), lds, as_stream(stream), xyz, n, seed_xyz,
                      rot, uidx, ucount, m, nseeds, spb, W, out);
   GN_CHECK_LAUNCH("crop_unique_mlp_pool");
+  return GN_OK;
+}
+
+// Set-abstraction tail with layer 1's feature part precomputed per point (gn_point_linear):
+// pfeat (B,N,c1) = W1f * feat + b1.  wpacked[0] holds only the K=8 coordinate block of layer 1
+// ([xyz(3) | 0]) with zero bias.  Bit-identical to gn_sa_group_mlp_pool.
+extern "C" int gn_sa_hoisted_mlp_pool(const float *xyz, const float *pfeat, const float *new_xyz, const int32_t *idx,
+                                      int b, int n, int np, int ns, float radius, const int *mlp,
+                                      const float *const *wpacked, const float *const *bias, float *out,
+                                      gn_stream_t stream) {
+  GN_REQUIRE(b >= 0 && n > 0 && np > 0 && ns > 0, "sa_hoisted_mlp_pool: bad sizes");
+  if (b == 0) return GN_OK;
+  GN_REQUIRE(xyz && pfeat && new_xyz && idx && mlp && wpacked && bias && out, "sa_hoisted_mlp_pool: null pointer");
+  GN_REQUIRE((long)n * 128 < 0x7fffffffL, "sa_hoisted_mlp_pool: n too large");
+  if (!(mlp[0] == 128 && mlp[1] == 128 && mlp[2] == 256 && (ns == 32 || ns == 16))) {
+    set_error("sa_hoisted_mlp_pool: unsupported configuration mlp=[%d,%d,%d] nsample=%d", mlp[0], mlp[1], mlp[2], ns);
+    return GN_ERR_INVALID_ARG;
+  }
+  const Mlp3Weights W{wpacked[0], bias[0], wpacked[1], bias[1], wpacked[2], bias[2]};
+  constexpr int TP = 128;
+  GN_REQUIRE(np % (TP / ns) == 0, "sa_hoisted_mlp_pool: npoint must be a multiple of %d", TP / ns);
+  const int ntiles = (int)((long)b * np / (TP / ns));
+  constexpr size_t lds = sizeof(float) * (2 * TP * lds_stride(128) + 2 * TP * lds_stride(8));
+  const int tpb = tiles_per_block(ntiles);
+  hipStream_t s = as_stream(stream);
+  int rc;
+  if (ns == 32) {
+    auto k = sa_hoist_kernel<128, 128, 256, 32>;
+    if ((rc = set_lds(k, lds, "sa_hoisted_mlp_pool"))) return rc;
+    hipLaunchKernelGGL(k, dim3((ntiles + tpb - 1) / tpb), dim3(MLP_THREADS), lds, s, xyz, n, pfeat, new_xyz, idx, np,
+                       ntiles, tpb, radius, W, out);
+  } else {
+    auto k = sa_hoist_kernel<128, 128, 256, 16>;
+    if ((rc = set_lds(k, lds, "sa_hoisted_mlp_pool"))) return rc;
+    hipLaunchKernelGGL(k, dim3((ntiles + tpb - 1) / tpb), dim3(MLP_THREADS), lds, s, xyz, n, pfeat, new_xyz, idx, np,
+                       ntiles, tpb, radius, W, out);
+  }
+  GN_CHECK_LAUNCH("sa_hoisted_mlp_pool");
   return GN_OK;
 }

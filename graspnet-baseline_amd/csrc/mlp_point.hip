@@ -112,6 +112,21 @@ __global__ __launch_bounds__(MLP_THREADS) void point_mlp_kernel(PointMlpArgs a, 
   }
 }
 
+// one linear layer per point, no activation: out (rows, COUT) = x (rows, CIN) * W^T + b
+template <int CIN, int COUT, int KC, int TP>
+__global__ __launch_bounds__(MLP_THREADS) void point_linear_kernel(const float *__restrict__ x,
+                                                                   const float *__restrict__ wp,
+                                                                   const float *__restrict__ bp, int nrows,
+                                                                   float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * TP;
+  load_plain_tile<CIN, TP>(smem, x, row0, nrows, tid);
+  __syncthreads();
+  StoreGlobal<false> e{out + (size_t)row0 * COUT, COUT, COUT, min(TP, nrows - row0), lane};
+  run_layer_stream<TP, CIN, COUT, KC>(wp, bp, smem, wave, lane, e);
+}
+
 template <int LOADER, int C0P, int C1P, int C1L, int C2P, int C2L, int C3P, int KC1, int KC2, int KC3, int TP,
           bool RELU_OUT>
 static int launch_point_mlp(const PointMlpArgs &a, hipStream_t s, const char *name) {
@@ -186,4 +201,33 @@ extern "C" int gn_heads_mlp(const float *x, int rows, int cin, int nout, const f
   a.x = x; a.out = out; a.ldo = 48; a.ncols_out = 48; a.nrows = rows;
   return launch_point_mlp<LOAD_PLAIN, 256, 256, 256, 256, 256, 64, 128, 128, 128, 64, false>(a, as_stream(stream),
                                                                                             "heads_mlp");
+}
+
+// Per-point linear map used to hoist layer 1 of a set-abstraction MLP: out (rows, cout) = x W^T + b.
+extern "C" int gn_point_linear(const float *x, int rows, int cin, int cout, const float *wpacked, const float *bias,
+                               float *out, gn_stream_t stream) {
+  GN_REQUIRE(rows >= 0, "point_linear: bad sizes");
+  if (rows == 0) return GN_OK;
+  GN_REQUIRE(x && wpacked && bias && out, "point_linear: null pointer");
+  constexpr int TP = 64;
+  hipStream_t s = as_stream(stream);
+  if (cin == 128 && cout == 128) {
+    auto k = point_linear_kernel<128, 128, 128, TP>;
+    constexpr size_t lds = sizeof(float) * TP * lds_stride(128);
+    hipLaunchKernelGGL(k, dim3((rows + TP - 1) / TP), dim3(MLP_THREADS), lds, s, x, wpacked, bias, rows, out);
+  } else if (cin == 256 && cout == 128) {
+    auto k = point_linear_kernel<256, 128, 128, TP>;
+    constexpr size_t lds = sizeof(float) * TP * lds_stride(256);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess) {
+      set_error("point_linear: cannot reserve LDS");
+      return GN_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(k, dim3((rows + TP - 1) / TP), dim3(MLP_THREADS), lds, s, x, wpacked, bias, rows, out);
+  } else {
+    set_error("point_linear: unsupported configuration cin=%d cout=%d", cin, cout);
+    return GN_ERR_INVALID_ARG;
+  }
+  GN_CHECK_LAUNCH("point_linear");
+  return GN_OK;
 }

@@ -44,6 +44,10 @@ SIGNATURES = {
     "gn_sa_group_mlp_pool": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                       _c_float, ctypes.POINTER(_c_int), ctypes.POINTER(_c_void_p),
                                       ctypes.POINTER(_c_void_p), _c_void_p, _c_void_p]),
+    "gn_point_linear": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "gn_sa_hoisted_mlp_pool": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                                        _c_float, ctypes.POINTER(_c_int), ctypes.POINTER(_c_void_p),
+                                        ctypes.POINTER(_c_void_p), _c_void_p, _c_void_p]),
     "gn_crop_group_mlp_pool": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                         ctypes.POINTER(_c_int), ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
                                         _c_void_p, _c_void_p]),

@@ -56,6 +56,8 @@ class GraspNet:
         self.timing = None        # set to {} to collect (start,end) HIP events per kernel launch
         # CloudCrop over de-duplicated (seed, point) rows (default) or over the four full index lists
         self.crop_unique = os.environ.get("GN_CROP_PATH", "unique") != "lists"
+        # SA2-4: layer 1's per-point part hoisted out of the per-neighbour MLP (bit-identical, fewer MFMAs)
+        self.sa_hoist = os.environ.get("GN_SA_PATH", "hoist") != "plain"
 
     def _run(self, name, status_fn):
         """Issue one C-ABI call; when self.timing is a dict, bracket it with events on the launch stream."""
@@ -149,10 +151,21 @@ class GraspNet:
                 self._run("ball_query[%d]" % (li + 1), lambda: lib.gn_ball_query(new_xyz.data_ptr(), lv_xyz.data_ptr(), B, lv_n, npoint, radius, nsample,
                                           idx.data_ptr(), st))
                 out = torch.empty((B, npoint, mlp[2]), dtype=f32, device=dev)
-                pk = self._packed["sa%d" % (li + 1)]
-                self._run("sa_group_mlp_pool[%d]" % (li + 1), lambda: lib.gn_sa_group_mlp_pool(lv_xyz.data_ptr(), L.ptr(lv_feat), new_xyz.data_ptr(), idx.data_ptr(),
-                                                 B, lv_n, npoint, nsample, c, radius, _ci(*mlp), pk.wptr, pk.bptr,
-                                                 out.data_ptr(), st))
+                if c > 0 and self.sa_hoist:
+                    # layer 1's feature part once per point, then gathered as the accumulator seed
+                    pre, pk = self._packed["sa%d_pre" % (li + 1)], self._packed["sa%d_hoist" % (li + 1)]
+                    pfeat = torch.empty((B, lv_n, mlp[0]), dtype=f32, device=dev)
+                    self._run("point_linear[%d]" % (li + 1), lambda: lib.gn_point_linear(
+                        lv_feat.data_ptr(), B * lv_n, c, mlp[0], pre.w[0].data_ptr(), pre.b[0].data_ptr(),
+                        pfeat.data_ptr(), st))
+                    self._run("sa_hoisted_mlp_pool[%d]" % (li + 1), lambda: lib.gn_sa_hoisted_mlp_pool(
+                        lv_xyz.data_ptr(), pfeat.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), B, lv_n, npoint, nsample,
+                        radius, _ci(*mlp), pk.wptr, pk.bptr, out.data_ptr(), st))
+                else:
+                    pk = self._packed["sa%d" % (li + 1)]
+                    self._run("sa_group_mlp_pool[%d]" % (li + 1), lambda: lib.gn_sa_group_mlp_pool(
+                        lv_xyz.data_ptr(), L.ptr(lv_feat), new_xyz.data_ptr(), idx.data_ptr(), B, lv_n, npoint, nsample, c,
+                        radius, _ci(*mlp), pk.wptr, pk.bptr, out.data_ptr(), st))
                 name = "sa%d" % (li + 1)
                 if li < 2:
                     end_points[name + "_inds"] = inds

@@ -158,6 +158,18 @@ int gn_sa_group_mlp_pool(const float *xyz, const float *feat, const float *new_x
                          const float *const *wpacked, const float *const *bias, float *out,
                          gn_stream_t stream);
 
+/* The same tail with layer 1's feature part hoisted out of the per-neighbour work: W1f*feat_j + b1 does
+ * not depend on the group, so it is computed once per point (gn_point_linear -> pfeat (B,N,mlp[0])) and
+ * gathered as the accumulators' initial value; wpacked[0]/bias[0] hold only the K=8 coordinate block of
+ * layer 1 ([xyz(3) | 0], zero bias).  Same k order => bit-identical to gn_sa_group_mlp_pool.
+ * Supported: mlp = {128,128,256}, ns in {32,16} (SA2-SA4 of models/backbone.py:39-64). */
+int gn_point_linear(const float *x, int rows, int cin, int cout, const float *wpacked, const float *bias,
+                    float *out, gn_stream_t stream);
+int gn_sa_hoisted_mlp_pool(const float *xyz, const float *pfeat, const float *new_xyz, const int32_t *idx,
+                           int b, int n, int np, int ns, float radius, const int *mlp,
+                           const float *const *wpacked, const float *const *bias, float *out,
+                           gn_stream_t stream);
+
 /* CloudCrop tail: group xyz by idx (B,M,ndepth,NS), subtract seed, rotate into the view frame,
  * SharedMLP[3,64,128,256], max-pool (pointnet2_utils.py:521-530 + models/modules.py:131-140).
  * out (B, M*ndepth, 256) channels-last, group order [seed][depth]. */

@@ -220,6 +220,18 @@ def test_crop_unique_equals_crop_lists(ref, net):
     print("unique rows per seed: mean %.1f max %d" % (float(ucnt.float().mean()), int(ucnt.max())))
 
 
+def test_sa_hoisted_equals_plain(net, state_dict, clouds):
+    """layer-1 hoisting keeps the k order of the plain grouped kernel: identical bits at every level"""
+    from graspnet_amd import GraspNet
+    plain = GraspNet().load_state_dict(state_dict)
+    plain.sa_hoist = False
+    a = net({"point_clouds": clouds.cuda()})
+    b = plain({"point_clouds": clouds.cuda()})
+    assert net.sa_hoist and not plain.sa_hoist
+    for k in ("sa1_features", "sa2_features", "sa3_features", "sa4_features", "fp2_features", "grasp_score_pred"):
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_crop_and_heads_isolated(ref, net):
     """CloudCrop + heads on the ORACLE's seeds/rotations/indices (no upstream flips)."""
     rep, _ = ref

@@ -282,6 +282,35 @@ class GraspNet:
         return grasps, counts
 
 
+class GraphedGraspNet:
+    """The whole forward + decode captured once as a hipGraph (torch.cuda.CUDAGraph) for a fixed (B,N):
+    a replay costs ~20 us of host time instead of ~25 launches.  Inputs are copied into a static buffer;
+    the returned end_points / grasps / counts are the graph's static output tensors (overwritten by the
+    next call).  Nothing in the C ABI allocates or synchronises, which is what makes the capture legal."""
+
+    def __init__(self, net, batch, points, warmup=2):
+        self.net = net
+        dev = net.device
+        self.static_in = torch.zeros((batch, points, 3), dtype=torch.float32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):       # first calls set kernel attributes / fill allocator pools
+                ep = net({"point_clouds": self.static_in})
+                net.decode_padded(ep)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.end_points = net({"point_clouds": self.static_in})
+            self.grasps, self.counts = net.decode_padded(self.end_points)
+
+    def __call__(self, point_clouds):
+        self.static_in.copy_(point_clouds[..., 0:3], non_blocking=True)
+        self.graph.replay()
+        return self.end_points, self.grasps, self.counts
+
+
 def _expected_keys():
     from . import synthetic
     return set(synthetic.make_state_dict(0, calibrated=False).keys())

@@ -24,6 +24,13 @@ def run(B, N, reps=5):
 
 run(1, 20000)
 run(8, 20000)
+from graspnet_amd import GraphedGraspNet
+for B in (1, 8):
+    cl = S.make_batch(1000, B, 20000).cuda()
+    gn = GraphedGraspNet(net, B, 20000)
+    gn(cl); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): gn(cl)
+    torch.cuda.synchronize(); print("hipGraph replay B=%d N=20000: %.3f ms/forward" % (B, (time.perf_counter() - t0) / 10 * 1e3))
 run(8, 50000, reps=3)
 run(1, 50000, reps=3)
 # config 4 op-level stress: ball_query M=2048 ns=64 r=0.04 on 50k points

@@ -327,6 +327,23 @@ def test_fps_prefix_shortcut_and_tie_fallback(net, oracle):
             assert identity
 
 
+def test_graph_captured_forward_matches_eager(net, clouds):
+    """the forward + decode is hipGraph-capturable (no allocation / sync inside the C ABI) and replays identically"""
+    from graspnet_amd import GraphedGraspNet
+    x = clouds.cuda()
+    ep = net({"point_clouds": x})
+    g0, c0 = net.decode_padded(ep)
+    gnet = GraphedGraspNet(net, batch=x.shape[0], points=x.shape[1])
+    for inp in (x, x.flip(0), x):
+        ep2, g1, c1 = gnet(inp)
+        torch.cuda.synchronize()
+    assert torch.equal(c0, c1) and torch.equal(g0, g1)
+    assert torch.equal(ep["sa1_inds"], ep2["sa1_inds"]) and torch.equal(ep["view_score"], ep2["view_score"])
+    ep3, g2, c2 = gnet(x.flip(0))
+    torch.cuda.synchronize()
+    assert torch.equal(c2, c0.flip(0)) and torch.equal(g2, g0.flip(0))
+
+
 def test_refuses_cpu_and_training(state_dict):
     from graspnet_amd import GraspNet
     with pytest.raises(NotImplementedError):

@@ -394,6 +394,269 @@ __global__ __launch_bounds__(1024) void fps_spatial_kernel(const float *__restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Region-interleaved variant (the default for 12 288 < positions <= 20 480).
+//
+// fps_spatial_kernel skips whole waves, but the waves that do run still pay for all their points,
+// and an iteration lasts as long as its busiest wave.  Here the cloud is cut into 64 regions of
+// equal population (8 x-slabs x 8 y-cells, same histogram / prefix / ticket construction), and
+// region (i,j) is given to wave (i + 3j) % 8 as that wave's slot group j.  The up-to-9 regions a new
+// sample can affect therefore land in different waves, each of which updates ONE 5-slot group (and
+// re-reduces only that group) while its other 7 groups keep their cached (max, rank).  Lanes 0..7
+// of a wave hold the state of its 8 groups (box, max, ~rank, tie), so the skip test of all groups
+// is one short vector sequence and the wave's candidate is a 16-lane DPP reduction.
+template <int PPT>
+__global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict__ xyz, int n, int m, int bs, int lg,
+                                                         int Q, unsigned qmagic, int32_t *__restrict__ idx,
+                                                         float *__restrict__ new_xyz, int32_t *__restrict__ tie_out) {
+  constexpr int NT = 512, NW = 8, G = 8, SG = PPT / G, CELL = 64 * PPT, NPT = (NW * CELL) / NT;
+  static_assert(PPT % G == 0, "slots per lane must split into 8 groups");
+  constexpr int YB = 1024;             // y bins per slab
+  extern __shared__ int lds_i[];
+  int *perm = lds_i;                   // [NW*CELL]
+  int *hx = perm + NW * CELL;          // [FPS_BINS]
+  int *hy = hx + FPS_BINS;             // [8][YB]
+  int *scr = hy + 8 * YB;              // [64]
+  __shared__ unsigned long long s_key[3];
+
+  const int b = blockIdx.x;
+  xyz += (size_t)b * n * 3;
+  idx += (size_t)b * m;
+  if (new_xyz) new_xyz += (size_t)b * m * 3;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int bmask = bs - 1;
+  auto rank_of = [&](int k) { return bitrev_bits(k & bmask, lg) * Q + (k >> lg); };
+
+  // ---- extent
+  float xmn = INFINITY, xmx = -INFINITY, ymn = INFINITY, ymx = -INFINITY;
+  for (int i = 0; i < NPT; ++i) {
+    const int k = t + i * NT;
+    if (k < n) {
+      const float x = xyz[k * 3 + 0], y = xyz[k * 3 + 1];
+      xmn = fminf(xmn, x); xmx = fmaxf(xmx, x); ymn = fminf(ymn, y); ymx = fmaxf(ymx, y);
+    }
+  }
+  float *scrf = reinterpret_cast<float *>(scr);
+  {
+    const float a0 = -wave_max(-xmn), a1 = wave_max(xmx), a2 = -wave_max(-ymn), a3 = wave_max(ymx);
+    if (lane == 0) { scrf[wave * 4 + 0] = a0; scrf[wave * 4 + 1] = a1; scrf[wave * 4 + 2] = a2; scrf[wave * 4 + 3] = a3; }
+  }
+  for (int i = t; i < FPS_BINS + 8 * YB; i += NT) hx[i] = 0;
+  for (int i = t; i < NW * CELL; i += NT) perm[i] = -1;
+  __syncthreads();
+  xmn = scrf[0]; xmx = scrf[1]; ymn = scrf[2]; ymx = scrf[3];
+  for (int w = 1; w < NW; ++w) {
+    xmn = fminf(xmn, scrf[w * 4 + 0]); xmx = fmaxf(xmx, scrf[w * 4 + 1]);
+    ymn = fminf(ymn, scrf[w * 4 + 2]); ymx = fmaxf(ymx, scrf[w * 4 + 3]);
+  }
+  __syncthreads();
+  const float sx = xmx > xmn ? (float)FPS_BINS / (xmx - xmn) : 0.f;
+  const float sy = ymx > ymn ? (float)YB / (ymx - ymn) : 0.f;
+  auto binx = [&](float x) { return min(FPS_BINS - 1, max(0, (int)((x - xmn) * sx))); };
+  auto biny = [&](float y) { return min(YB - 1, max(0, (int)((y - ymn) * sy))); };
+  const int T2 = (n + 63) / 64;        // points per region (<= 64*SG because 64*64*SG >= n)
+  const int T1 = 8 * T2;               // points per x slab
+
+  // exclusive scan helpers for 512 threads
+  auto scan = [&](int *a, int len) {   // len = multiple of NT
+    const int per = len / NT;
+    int loc = 0;
+    for (int e = 0; e < per; ++e) loc += a[t * per + e];
+    int incl = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) scr[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += scr[w];
+    int run = woff + incl - loc;
+    for (int e = 0; e < per; ++e) {
+      const int v = a[t * per + e];
+      a[t * per + e] = run;
+      run += v;
+    }
+    __syncthreads();
+  };
+
+  // ---- x slabs
+  for (int i = 0; i < NPT; ++i) {
+    const int k = t + i * NT;
+    if (k < n) atomicAdd(&hx[binx(xyz[k * 3 + 0])], 1);
+  }
+  __syncthreads();
+  scan(hx, FPS_BINS);
+  unsigned long long slabs_lo = 0ULL, slabs_hi = 0ULL;   // 3 bits per owned point (NPT <= 40)
+  for (int i = 0; i < NPT; ++i) {
+    const int k = t + i * NT;
+    if (k < n) {
+      const int q = atomicAdd(&hx[binx(xyz[k * 3 + 0])], 1);
+      const unsigned long long sl = (unsigned long long)min(q / T1, 7);
+      if (i < 21) slabs_lo |= sl << (3 * i); else slabs_hi |= sl << (3 * (i - 21));
+      atomicAdd(&hy[(int)sl * YB + biny(xyz[k * 3 + 1])], 1);
+    }
+  }
+  __syncthreads();
+  for (int sl = 0; sl < 8; ++sl) scan(hy + sl * YB, YB);
+  for (int i = 0; i < NPT; ++i) {
+    const int k = t + i * NT;
+    if (k < n) {
+      const int sl = (int)((i < 21 ? slabs_lo >> (3 * i) : slabs_hi >> (3 * (i - 21))) & 7ULL);
+      const int q2 = atomicAdd(&hy[sl * YB + biny(xyz[k * 3 + 1])], 1);
+      const int cy = min(q2 / T2, 7);
+      const int r = min(q2 - cy * T2, 64 * SG - 1);
+      const int w = (sl + 3 * cy) & 7;                 // region (sl,cy) -> wave, group cy
+      perm[w * CELL + (cy * SG + r / 64) * 64 + (r & 63)] = k;
+    }
+  }
+  __syncthreads();
+
+  // ---- this lane's points; lanes 0..7 keep the state of the wave's 8 groups
+  float px[PPT], py[PPT], pz[PPT], tmp[PPT];
+  float gx0 = INFINITY, gx1 = -INFINITY, gy0 = INFINITY, gy1 = -INFINITY, gz0 = INFINITY, gz1 = -INFINITY;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float x0 = INFINITY, x1_ = -INFINITY, y0 = INFINITY, y1_ = -INFINITY, z0 = INFINITY, z1_ = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < SG; ++q) {
+      const int s = g * SG + q;
+      const int k = perm[wave * CELL + s * 64 + lane];
+      float x = 0.f, y = 0.f, z = 0.f, t0 = -1.0f;
+      if (k >= 0) {
+        x = xyz[k * 3 + 0]; y = xyz[k * 3 + 1]; z = xyz[k * 3 + 2];
+        const float mag = (x * x) + (y * y) + (z * z);
+        t0 = ((double)mag <= 1e-3) ? -1.0f : 1e10f;     // sampling_gpu.cu:105-106, sampling.cpp:78-80
+        x0 = fminf(x0, x); x1_ = fmaxf(x1_, x); y0 = fminf(y0, y); y1_ = fmaxf(y1_, y);
+        z0 = fminf(z0, z); z1_ = fmaxf(z1_, z);
+      }
+      px[s] = x; py[s] = y; pz[s] = z; tmp[s] = t0;
+    }
+    x0 = -wave_max(-x0); x1_ = wave_max(x1_); y0 = -wave_max(-y0); y1_ = wave_max(y1_);
+    z0 = -wave_max(-z0); z1_ = wave_max(z1_);
+    if (lane == g) { gx0 = x0; gx1 = x1_; gy0 = y0; gy1 = y1_; gz0 = z0; gz1 = z1_; }
+  }
+  float gmax = INFINITY;       // cached max of the group's running distances (inf = not computed yet)
+  unsigned gkeylo = 0u;        // ~rank of the group's candidate
+  bool gtie = false;           // the group's max is shared by different locations
+
+  float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
+  if (t == 0) {
+    idx[0] = 0;
+    if (new_xyz) { new_xyz[0] = x1; new_xyz[1] = y1; new_xyz[2] = z1; }
+  }
+  if (t < 3) s_key[t] = 0ULL;
+  __syncthreads();
+
+  int first_tie = 0x7fffffff;
+  for (int j = 1; j < m; ++j) {
+    // ---- which of this wave's groups can change?  (lane g tests group g)
+    const float ex = fmaxf(fmaxf(gx0 - x1, x1 - gx1), 0.f);
+    const float ey = fmaxf(fmaxf(gy0 - y1, y1 - gy1), 0.f);
+    const float ez = fmaxf(fmaxf(gz0 - z1, z1 - gz1), 0.f);
+    const float lb = (ex * ex + ey * ey + ez * ez) * 0.99999f;
+    const unsigned amask = (unsigned)__ballot(lane < G && !(lb >= gmax)) & 0xffu;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (!((amask >> g) & 1u)) continue;      // wave-uniform
+      float best = -1.0f;
+      int bslot = 0;
+      bool tie = false;
+#pragma unroll
+      for (int q = 0; q < SG; ++q) {
+        const int s = g * SG + q;
+        const float dx = px[s] - x1, dy = py[s] - y1, dz = pz[s] - z1;
+        const float d = dx * dx + dy * dy + dz * dz;
+        const float d2 = vmin(d, tmp[s]);
+        tmp[s] = d2;
+        tie = tie || (d2 == best);
+        const bool gt = d2 > best;
+        best = gt ? d2 : best;
+        bslot = gt ? s : bslot;
+      }
+      const float rmax = row16_max_fast(best);
+      const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rmax), 0));
+      const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rmax), 16));
+      const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rmax), 32));
+      const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rmax), 48));
+      const float wmax = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+      const bool mine = best == wmax;
+      const unsigned long long eq = __ballot(mine);
+      int wrank = 0;
+      bool ctie = false;
+      if (wmax >= 0.0f) {
+        if (__popcll(eq) > 1 || __ballot(mine && tie)) {
+          // rare: several points of the group share the maximum -> reference order = smallest rank;
+          // duplicates of one location are harmless, different locations are recorded as a tie
+          int myr = 0x7fffffff;
+          float lx0 = INFINITY, lx1 = -INFINITY, ly0 = INFINITY, ly1 = -INFINITY, lz0 = INFINITY, lz1 = -INFINITY;
+#pragma unroll
+          for (int q = 0; q < SG; ++q) {
+            const int s = g * SG + q;
+            if (tmp[s] == wmax) {
+              const int k = perm[wave * CELL + s * 64 + lane];
+              if (k >= 0) {
+                myr = min(myr, rank_of(k));
+                lx0 = fminf(lx0, px[s]); lx1 = fmaxf(lx1, px[s]); ly0 = fminf(ly0, py[s]); ly1 = fmaxf(ly1, py[s]);
+                lz0 = fminf(lz0, pz[s]); lz1 = fmaxf(lz1, pz[s]);
+              }
+            }
+          }
+          wrank = wave_min_i(myr);
+          ctie = (-wave_max(-lx0) != wave_max(lx1)) || (-wave_max(-ly0) != wave_max(ly1)) ||
+                 (-wave_max(-lz0) != wave_max(lz1));
+        } else {
+          const int src = __ffsll((long long)eq) - 1;
+          const int kc = perm[wave * CELL + bslot * 64 + lane];
+          wrank = rank_of(__builtin_amdgcn_readlane(kc, src));
+        }
+      }
+      if (lane == g) {
+        gmax = wmax;
+        gkeylo = wmax >= 0.0f ? (unsigned)(~wrank) : 0u;
+        gtie = ctie;
+      }
+    }
+    // ---- the wave's candidate: best of its 8 groups (largest value, then smallest rank)
+    const float gv = lane < G ? gmax : -2.0f;
+    const float wm = __builtin_bit_cast(
+        float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row16_max_fast(gv))));
+    const bool gm = lane < G && gmax == wm;
+    const unsigned klo = __builtin_amdgcn_readfirstlane(row16_max_u32_fast(gm ? gkeylo : 0u));
+    const unsigned long long gmb = __ballot(gm);
+    // a tie inside the winning group, or two groups with the same maximum (conservatively a tie)
+    const bool c_tie = (__ballot(gm && gtie) != 0ULL) || __popcll(gmb) > 1;
+    const unsigned long long c_key = wm >= 0.0f ? (((unsigned long long)__float_as_uint(wm) << 32) | klo) : 0ULL;
+
+    const int slot = j % 3;
+    if (lane == 0) {
+      atomicMax(&s_key[slot], c_key);
+      if (t == 0) s_key[(j + 1) % 3] = 0ULL;
+    }
+    __syncthreads();
+    const unsigned long long gk = s_key[slot];
+    const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gk);
+    if (gk == 0ULL || ((unsigned)(c_key >> 32) == (unsigned)(gk >> 32) && c_key != 0ULL && (c_tie || c_key != gk)))
+      first_tie = min(first_tie, j);
+    int k = gk != 0ULL ? pos_to_k((int)~glo, bs, lg, Q, qmagic, n) : 0;   // rank -> index
+    k = __builtin_amdgcn_readfirstlane(k < 0 ? 0 : k);
+    x1 = xyz[k * 3 + 0]; y1 = xyz[k * 3 + 1]; z1 = xyz[k * 3 + 2];
+    if (t == 0) {
+      idx[j] = k;
+      if (new_xyz) { new_xyz[j * 3 + 0] = x1; new_xyz[j * 3 + 1] = y1; new_xyz[j * 3 + 2] = z1; }
+    }
+  }
+  if (tie_out) {
+    __shared__ int s_tie;
+    if (t == 0) s_tie = 0x7fffffff;
+    __syncthreads();
+    if (lane == 0) atomicMin(&s_tie, first_tie);
+    __syncthreads();
+    if (t == 0) tie_out[b] = s_tie;
+  }
+}
+
 // Large clouds (24 576 < positions <= 65 536): the running min-distances still live in registers for
 // the whole chain (PPT per lane); the coordinates are tiered: RS slots per lane in registers, LS
 // slots in LDS (SoA [slot][thread], conflict-free), the rest streamed every iteration from a
@@ -620,7 +883,7 @@ extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m,
   const unsigned qmagic = Q == 1 ? 0xffffffffu : (unsigned)((0x100000000ull + Q - 1) / Q);
   hipStream_t s = as_stream(stream);
   bool tie_written = false;
-  static const int variant = []() { const char *e = getenv("GN_FPS_VARIANT"); return e ? atoi(e) : 3; }();
+  static const int variant = []() { const char *e = getenv("GN_FPS_VARIANT"); return e ? atoi(e) : 4; }();
 #define GN_FPS_LAUNCH(NT, PPT)                                                                    \
   hipLaunchKernelGGL((fps_reg_kernel<NT, PPT>), dim3(b), dim3(NT), 0, s, xyz, n, m, bs, lg, Q, qmagic, \
                      idx, new_xyz, prefix_ok)
@@ -644,6 +907,20 @@ extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m,
                        tie_out);                                                                            \
     tie_written = true;                                                                                     \
   } while (0)
+#define GN_FPS_REGION(PPT)                                                                                  \
+  do {                                                                                                      \
+    auto kern = fps_region_kernel<PPT>;                                                                     \
+    const int lds = (8 * 64 * PPT + FPS_BINS + 8 * 1024 + 64) * (int)sizeof(int);                           \
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            lds) != hipSuccess) {                                                           \
+      set_error("furthest_point_sampling: cannot reserve %d bytes of LDS", lds);                            \
+      return GN_ERR_LAUNCH;                                                                                 \
+    }                                                                                                       \
+    hipLaunchKernelGGL(kern, dim3(b), dim3(512), lds, s, xyz, n, m, bs, lg, Q, qmagic, idx, new_xyz, tie_out); \
+    tie_written = true;                                                                                     \
+  } while (0)
+  else if (need > 1024 * 12 && need <= 1024 * 16 && variant == 4) GN_FPS_REGION(32);
+  else if (need > 1024 * 16 && need <= 1024 * 20 && variant == 4) GN_FPS_REGION(40);
   else if (need > 1024 * 12 && need <= 1024 * 16 && variant == 3) GN_FPS_SPATIAL(16);
   else if (need > 1024 * 16 && need <= 1024 * 20 && variant == 3) GN_FPS_SPATIAL(20);
   else if (need <= 512 * 40 && variant == 1) GN_FPS_LAUNCH(512, 40);

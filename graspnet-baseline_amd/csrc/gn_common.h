@@ -59,6 +59,22 @@ __device__ __forceinline__ float row16_max_fast(float v) {
   return v;
 }
 
+// unsigned-integer flavour of row16_max_fast
+__device__ __forceinline__ unsigned row16_max_u32_fast(unsigned v) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return v;
+}
+
 // max over each 16-lane row, result in every lane of the row
 __device__ __forceinline__ float row16_max(float v) {
   v = fmaxf(v, dpp_f<0xB1>(v));   // quad_perm [1,0,3,2]

@@ -1,0 +1,442 @@
+// grid.hip -- uniform-grid acceleration of the neighbour queries (ball / cylinder), exact semantics.
+//
+// The reference's queries return the FIRST nsample hits IN INDEX ORDER (ball_query_gpu.cu:30-47,
+// cylinder_query_gpu.cu:35-54), which is why query.hip scans the whole cloud in order.  Here the
+// cloud is binned once per level into a uniform grid whose cells are at least `reach` wide (reach =
+// ball radius, or the radius of the sphere that contains the cylinder), so every hit of a centre lies
+// in the 3x3x3 cells around it (40x fewer candidates at N=20 000, r=0.04).  Candidates are then visited
+// in grid order, NOT index order, so each wave keeps the nsample smallest hit indices seen so far as
+// a sorted 64-lane register (bitonic sort of each batch of 64 hits + bitonic merge, all by shuffles);
+// the final register is exactly the reference's list.  The hit predicate is evaluated on the same
+// float expression as the reference.
+#include "gn_common.h"
+
+namespace gn {
+
+constexpr int GRID_MAX_DIM = 32;                      // cells per axis (x,y); z uses GRID_MAX_DIMZ
+constexpr int GRID_MAX_DIMZ = 16;
+constexpr int GRID_MAX_CELLS = GRID_MAX_DIM * GRID_MAX_DIM * GRID_MAX_DIMZ;   // 16384
+
+// per-cloud header written by the build kernel (floats/ints, 16 words)
+struct GridHeader {
+  float minx, miny, minz;
+  float invx, invy, invz;    // 1 / cell size per axis
+  int dx, dy, dz;            // cells per axis
+  int pad[7];
+};
+
+__device__ __forceinline__ int cell_coord(float v, float mn, float inv, int dim) {
+  const int c = (int)((v - mn) * inv);
+  return c < 0 ? 0 : (c >= dim ? dim - 1 : c);
+}
+
+// one workgroup per cloud: extent -> cell histogram (LDS) -> exclusive scan -> ticket scatter.
+// outputs per cloud: header, cell_start[GRID_MAX_CELLS + 1], sorted xyz (n,3), sorted original index (n)
+__global__ __launch_bounds__(1024) void grid_build_kernel(const float *__restrict__ xyz, int n, float reach,
+                                                          GridHeader *__restrict__ hdr, int *__restrict__ cell_start,
+                                                          float *__restrict__ sxyz, int32_t *__restrict__ sidx) {
+  __shared__ int s_cnt[GRID_MAX_CELLS];
+  __shared__ float s_red[16 * 6];
+  __shared__ int s_scan[16];
+  const int b = blockIdx.x;
+  xyz += (size_t)b * n * 3;
+  hdr += b;
+  cell_start += (size_t)b * (GRID_MAX_CELLS + 1);
+  sxyz += (size_t)b * n * 3;
+  sidx += (size_t)b * n;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int k = t; k < n; k += 1024)
+    for (int a = 0; a < 3; ++a) {
+      const float v = xyz[k * 3 + a];
+      mn[a] = fminf(mn[a], v);
+      mx[a] = fmaxf(mx[a], v);
+    }
+  for (int a = 0; a < 3; ++a) {
+    const float lo = -wave_max(-mn[a]), hi = wave_max(mx[a]);
+    if (lane == 0) { s_red[wave * 6 + a] = lo; s_red[wave * 6 + 3 + a] = hi; }
+  }
+  for (int i = t; i < GRID_MAX_CELLS; i += 1024) s_cnt[i] = 0;
+  __syncthreads();
+  for (int a = 0; a < 3; ++a) {
+    mn[a] = s_red[a]; mx[a] = s_red[3 + a];
+    for (int w = 1; w < 16; ++w) { mn[a] = fminf(mn[a], s_red[w * 6 + a]); mx[a] = fmaxf(mx[a], s_red[w * 6 + 3 + a]); }
+  }
+  // cell size per axis: at least `reach` (+0.1 % so that rounding in the coordinate -> cell map can never
+  // put a point within `reach` of a centre more than one cell away), larger if the axis would need
+  // more than the table holds
+  const float h = reach * 1.001f;
+  int dim[3];
+  float inv[3];
+  const int cap[3] = {GRID_MAX_DIM, GRID_MAX_DIM, GRID_MAX_DIMZ};
+  for (int a = 0; a < 3; ++a) {
+    const float ext = fmaxf(mx[a] - mn[a], 0.f);
+    int d = (int)(ext / h) + 1;
+    float cs = h;
+    if (d > cap[a]) { d = cap[a]; cs = ext / (float)cap[a] * 1.001f; }
+    dim[a] = d;
+    inv[a] = 1.0f / cs;
+  }
+  if (t == 0) {
+    hdr->minx = mn[0]; hdr->miny = mn[1]; hdr->minz = mn[2];
+    hdr->invx = inv[0]; hdr->invy = inv[1]; hdr->invz = inv[2];
+    hdr->dx = dim[0]; hdr->dy = dim[1]; hdr->dz = dim[2];
+  }
+  auto cell_of = [&](int k) {
+    const int cx = cell_coord(xyz[k * 3 + 0], mn[0], inv[0], dim[0]);
+    const int cy = cell_coord(xyz[k * 3 + 1], mn[1], inv[1], dim[1]);
+    const int cz = cell_coord(xyz[k * 3 + 2], mn[2], inv[2], dim[2]);
+    return (cz * dim[1] + cy) * dim[0] + cx;   // x fastest: the 3 x-neighbours of a cell are contiguous
+  };
+  for (int k = t; k < n; k += 1024) atomicAdd(&s_cnt[cell_of(k)], 1);
+  __syncthreads();
+  // exclusive scan of GRID_MAX_CELLS counters (16 per thread)
+  {
+    constexpr int PER = GRID_MAX_CELLS / 1024;
+    int loc = 0;
+    for (int e = 0; e < PER; ++e) loc += s_cnt[t * PER + e];
+    int incl = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_scan[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_scan[w];
+    int run = woff + incl - loc;
+    for (int e = 0; e < PER; ++e) {
+      const int v = s_cnt[t * PER + e];
+      s_cnt[t * PER + e] = run;
+      cell_start[t * PER + e] = run;
+      run += v;
+    }
+    if (t == 1023) cell_start[GRID_MAX_CELLS] = run;
+    __syncthreads();
+  }
+  for (int k = t; k < n; k += 1024) {
+    const int pos = atomicAdd(&s_cnt[cell_of(k)], 1);
+    sxyz[pos * 3 + 0] = xyz[k * 3 + 0];
+    sxyz[pos * 3 + 1] = xyz[k * 3 + 1];
+    sxyz[pos * 3 + 2] = xyz[k * 3 + 2];
+    sidx[pos] = k;
+  }
+}
+
+// ---- 64-lane sorted-set helpers (one key per lane, ascending across lanes) --------------------------
+__device__ __forceinline__ int cmpx(int v, int partner_mask, bool keep_min, int lane) {
+  const int o = __shfl_xor(v, partner_mask);
+  (void)lane;
+  return keep_min ? min(v, o) : max(v, o);
+}
+// full bitonic sort of 64 keys
+__device__ __forceinline__ int sort64(int v, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const bool up = (lane & k) == 0 || k == 64;
+      const bool lower = (lane & j) == 0;
+      v = cmpx(v, j, lower == up, lane);
+    }
+  return v;
+}
+// a, b ascending -> the 64 smallest of their union, ascending
+__device__ __forceinline__ int merge_low64(int a, int b, int lane) {
+  const int br = __shfl(b, 63 - lane);
+  int v = min(a, br);               // bitonic sequence holding the 64 smallest
+#pragma unroll
+  for (int j = 32; j > 0; j >>= 1) v = cmpx(v, j, (lane & j) == 0, lane);
+  return v;
+}
+
+constexpr int GQ_WAVES = 4;
+
+// ball query on the grid.  One wave per centre.  nsample <= 64.
+__global__ __launch_bounds__(GQ_WAVES * 64) void ball_grid_kernel(const float *__restrict__ new_xyz,
+                                                                  const GridHeader *__restrict__ hdr,
+                                                                  const int *__restrict__ cell_start,
+                                                                  const float *__restrict__ sxyz,
+                                                                  const int32_t *__restrict__ sidx, int n, int m,
+                                                                  float radius, int nsample,
+                                                                  int32_t *__restrict__ idx) {
+  __shared__ int s_queue[GQ_WAVES][128];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = blockIdx.x * GQ_WAVES + wv;
+  if (j >= m) return;
+  const GridHeader H = hdr[b];
+  cell_start += (size_t)b * (GRID_MAX_CELLS + 1);
+  sxyz += (size_t)b * n * 3;
+  sidx += (size_t)b * n;
+  const float *c = new_xyz + ((size_t)b * m + j) * 3;
+  int32_t *row = idx + ((size_t)b * m + j) * nsample;
+  const float cx = c[0], cy = c[1], cz = c[2];
+  const float radius2 = radius * radius;   // ball_query_gpu.cu:27
+  // centre's cell from UNCLAMPED coordinates (a centre may lie outside the cloud's box)
+  const int ccx = (int)floorf((cx - H.minx) * H.invx), ccy = (int)floorf((cy - H.miny) * H.invy),
+            ccz = (int)floorf((cz - H.minz) * H.invz);
+  // cell window: cells are at least 1.001 x the build reach wide; a grid built for a smaller reach just
+  // widens the window
+  const int rx = (int)(radius * H.invx) + 1, ry = (int)(radius * H.invy) + 1, rz = (int)(radius * H.invz) + 1;
+  const int x0 = max(ccx - rx, 0), x1 = min(ccx + rx, H.dx - 1);
+  int *queue = s_queue[wv];
+  int best = 0x7fffffff;    // ascending across lanes: the nsample... 64 smallest hit indices so far
+  int qn = 0;               // hits waiting in the queue
+  int total = 0;
+  if (x0 <= x1) {
+    for (int zz = max(ccz - rz, 0); zz <= min(ccz + rz, H.dz - 1); ++zz)
+      for (int yy = max(ccy - ry, 0); yy <= min(ccy + ry, H.dy - 1); ++yy) {
+        const int cb = (zz * H.dy + yy) * H.dx;
+        const int p0 = cell_start[cb + x0], p1 = cell_start[cb + x1 + 1];
+        for (int p = p0; p < p1; p += 64) {
+          const int q = p + lane;
+          bool hit = false;
+          int k = 0;
+          if (q < p1) {
+            const float px = sxyz[q * 3 + 0], py = sxyz[q * 3 + 1], pz = sxyz[q * 3 + 2];
+            // ball_query_gpu.cu:33-38
+            const float d2 = (cx - px) * (cx - px) + (cy - py) * (cy - py) + (cz - pz) * (cz - pz);
+            hit = d2 < radius2;
+            k = sidx[q];
+          }
+          const unsigned long long mask = __ballot(hit);
+          if (mask) {
+            const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            if (hit) queue[pos] = k;
+            const int add = __popcll(mask);
+            qn += add;
+            total += add;
+            if (qn >= 64) {           // fold the oldest 64 queued hits into the sorted set
+              __builtin_amdgcn_wave_barrier();
+              const int v = sort64(queue[lane], lane);
+              best = merge_low64(best, v, lane);
+              const int rest = queue[64 + lane];
+              __builtin_amdgcn_wave_barrier();
+              if (lane < qn - 64) queue[lane] = rest;
+              qn -= 64;
+            }
+          }
+        }
+      }
+  }
+  if (qn > 0) {
+    __builtin_amdgcn_wave_barrier();
+    const int v = sort64(lane < qn ? queue[lane] : 0x7fffffff, lane);
+    best = merge_low64(best, v, lane);
+  }
+  // first `nsample` hits in index order; unfilled slots repeat the first hit; no hit -> zeros
+  const int cnt = min(total, nsample);
+  const int first = total > 0 ? __builtin_amdgcn_readfirstlane(best) : 0;
+  if (lane < nsample) row[lane] = lane < cnt ? best : first;
+}
+
+// CloudCrop's four nested cylinders on the grid -> the de-duplicated list of gn_cylinder_query_unique
+// (same entries and masks; entries grouped by minimum depth instead of index order, which the
+// consumer -- a max-pool over rows -- does not depend on).
+//
+// A base hit (inside the radius, above hmin) with x_rot < hmax[d] first at d = dmin belongs to the depth
+// lists d >= dmin, each of which keeps its 64 smallest indices.  Per depth the wave keeps a sorted
+// register of keys (index << 2 | dmin).  Let thr_d be the 64th smallest key of depth d (inf if it has
+// fewer hits): thr_0 >= thr_1 >= thr_2 >= thr_3 because the candidate sets grow with d.  Hence an entry
+// is in SOME list iff it is in the list of its own dmin, and it is in exactly the lists
+// d = dmin .. max{d : key <= thr_d}: the union is the disjoint union over d of {e in L_d : dmin(e) = d}
+// and the mask follows from three threshold compares.
+template <int ND>
+__global__ __launch_bounds__(GQ_WAVES * 64) void cylinder_unique_grid_kernel(
+    const float *__restrict__ new_xyz, const float *__restrict__ rot, const GridHeader *__restrict__ hdr,
+    const int *__restrict__ cell_start, const float *__restrict__ sxyz, const int32_t *__restrict__ sidx, int n, int m,
+    float radius, float hmin, float hmax0, float hmax1, float hmax2, float hmax3, float reach, int nsample,
+    int32_t *__restrict__ uidx, int32_t *__restrict__ ucount) {
+  static_assert(ND == 4, "4 depths");
+  __shared__ int s_queue[GQ_WAVES][ND][128];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = blockIdx.x * GQ_WAVES + wv;
+  if (j >= m) return;
+  const GridHeader H = hdr[b];
+  cell_start += (size_t)b * (GRID_MAX_CELLS + 1);
+  sxyz += (size_t)b * n * 3;
+  sidx += (size_t)b * n;
+  const float *c = new_xyz + ((size_t)b * m + j) * 3;
+  const float *r = rot + ((size_t)b * m + j) * 9;
+  int32_t *row = uidx + ((size_t)b * m + j) * ND * nsample;
+  const float cx = c[0], cy = c[1], cz = c[2];
+  const float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7], r8 = r[8];
+  const float radius2 = radius * radius;
+  const float hmax[4] = {hmax0, hmax1, hmax2, hmax3};
+  const int ccx = (int)floorf((cx - H.minx) * H.invx), ccy = (int)floorf((cy - H.miny) * H.invy),
+            ccz = (int)floorf((cz - H.minz) * H.invz);
+  const int rx = (int)(reach * H.invx) + 1, ry = (int)(reach * H.invy) + 1, rz = (int)(reach * H.invz) + 1;
+  const int x0 = max(ccx - rx, 0), x1 = min(ccx + rx, H.dx - 1);
+  int best[ND], qn[ND], total[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d) { best[d] = 0x7fffffff; qn[d] = 0; total[d] = 0; }
+
+  auto fold = [&](int d) {     // oldest 64 queued keys of depth d -> sorted set
+    int *q = s_queue[wv][d];
+    __builtin_amdgcn_wave_barrier();
+    const int v = sort64(q[lane], lane);
+    best[d] = merge_low64(best[d], v, lane);
+    const int rest = q[64 + lane];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < qn[d] - 64) q[lane] = rest;
+    qn[d] -= 64;
+  };
+
+  if (x0 <= x1) {
+    for (int zz = max(ccz - rz, 0); zz <= min(ccz + rz, H.dz - 1); ++zz)
+      for (int yy = max(ccy - ry, 0); yy <= min(ccy + ry, H.dy - 1); ++yy) {
+        const int cb = (zz * H.dy + yy) * H.dx;
+        const int p0 = cell_start[cb + x0], p1 = cell_start[cb + x1 + 1];
+        for (int p = p0; p < p1; p += 64) {
+          const int q = p + lane;
+          bool base = false;
+          float x_rot = 0.f;
+          int k = 0;
+          if (q < p1) {
+            // cylinder_query_gpu.cu:36-46
+            const float x = sxyz[q * 3 + 0] - cx, y = sxyz[q * 3 + 1] - cy, z = sxyz[q * 3 + 2] - cz;
+            x_rot = r0 * x + r3 * y + r6 * z;
+            const float y_rot = r1 * x + r4 * y + r7 * z;
+            const float z_rot = r2 * x + r5 * y + r8 * z;
+            const float d2 = y_rot * y_rot + z_rot * z_rot;
+            base = d2 < radius2 && x_rot > hmin && x_rot < hmax[ND - 1];
+            k = sidx[q];
+          }
+          if (!__ballot(base)) continue;
+          const int dmin = x_rot < hmax[0] ? 0 : (x_rot < hmax[1] ? 1 : (x_rot < hmax[2] ? 2 : 3));
+          const int key = (k << 2) | dmin;
+#pragma unroll
+          for (int d = 0; d < ND; ++d) {
+            const bool hit = base && dmin <= d;
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {
+              const int pos = qn[d] + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+              if (hit) s_queue[wv][d][pos] = key;
+              const int add = __popcll(mask);
+              qn[d] += add;
+              total[d] += add;
+              if (qn[d] >= 64) fold(d);
+            }
+          }
+        }
+      }
+  }
+#pragma unroll
+  for (int d = 0; d < ND; ++d)
+    if (qn[d] > 0) {
+      __builtin_amdgcn_wave_barrier();
+      const int v = sort64(lane < qn[d] ? s_queue[wv][d][lane] : 0x7fffffff, lane);
+      best[d] = merge_low64(best[d], v, lane);
+    }
+  // thresholds: the largest key each depth's list accepts
+  int thr[ND], cnt[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d) {
+    cnt[d] = min(total[d], nsample);
+    thr[d] = total[d] >= nsample ? __builtin_amdgcn_readlane(best[d], nsample - 1) : 0x7fffffff;
+  }
+  // depths without any hit: the reference row is all zeros = point 0 repeated
+  unsigned emask = 0;
+#pragma unroll
+  for (int d = 0; d < ND; ++d) emask |= (total[d] == 0 ? 1u : 0u) << d;
+  int ucnt = 0;
+  bool zero_in_union = false;
+#pragma unroll
+  for (int d = 0; d < ND; ++d) {
+    const int key = best[d];
+    const bool own = lane < cnt[d] && (key & 3) == d;       // entry whose minimum depth is d
+    unsigned mk = 0;
+#pragma unroll
+    for (int e = d; e < ND; ++e) mk |= (key <= thr[e] ? 1u : 0u) << e;
+    const int k = key >> 2;
+    const bool is_zero = own && k == 0;
+    if (is_zero) mk |= emask;
+    if (__ballot(is_zero)) zero_in_union = true;
+    const unsigned long long um = __ballot(own);
+    const int slot = ucnt + __builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
+    if (own) row[slot] = k | (int)(mk << 28);
+    ucnt += __popcll(um);
+  }
+  if (emask && !zero_in_union) {
+    if (lane == 0) row[ucnt] = 0 | (int)(emask << 28);
+    ucnt += 1;
+  }
+  if (lane == 0) ucount[(size_t)b * m + j] = ucnt;
+}
+
+}  // namespace gn
+
+using namespace gn;
+
+extern "C" size_t gn_grid_workspace_bytes(int b, int n) {
+  if (b <= 0 || n <= 0) return 0;
+  return (size_t)b * (sizeof(GridHeader) + (size_t)(GRID_MAX_CELLS + 1) * 4 + (size_t)n * 16);
+}
+
+static void grid_carve(void *ws, int b, int n, GridHeader **hdr, int **cs, float **sxyz, int32_t **sidx) {
+  char *p = (char *)ws;
+  *hdr = (GridHeader *)p;
+  p += (size_t)b * sizeof(GridHeader);
+  *cs = (int *)p;
+  p += (size_t)b * (GRID_MAX_CELLS + 1) * 4;
+  *sxyz = (float *)p;
+  p += (size_t)b * n * 12;
+  *sidx = (int32_t *)p;
+}
+
+extern "C" int gn_grid_build(const float *xyz, int b, int n, float reach, void *workspace, gn_stream_t stream) {
+  GN_REQUIRE(b >= 0 && n >= 1 && reach > 0.f, "grid_build: bad sizes");
+  if (b == 0) return GN_OK;
+  GN_REQUIRE(xyz && workspace, "grid_build: null pointer");
+  GN_REQUIRE((long)n * 3 < 0x7fffffffL, "grid_build: n too large");
+  GridHeader *hdr; int *cs; float *sxyz; int32_t *sidx;
+  grid_carve(workspace, b, n, &hdr, &cs, &sxyz, &sidx);
+  hipLaunchKernelGGL(grid_build_kernel, dim3(b), dim3(1024), 0, as_stream(stream), xyz, n, reach, hdr, cs, sxyz, sidx);
+  GN_CHECK_LAUNCH("grid_build");
+  return GN_OK;
+}
+
+extern "C" int gn_ball_query_grid(const float *new_xyz, const void *grid, int b, int n, int m, float radius,
+                                  int nsample, int32_t *idx, gn_stream_t stream) {
+  GN_REQUIRE(b >= 0 && n >= 1 && m >= 0 && nsample >= 1 && nsample <= 64, "ball_query_grid: bad sizes (nsample <= 64)");
+  if (b == 0 || m == 0) return GN_OK;
+  GN_REQUIRE(new_xyz && grid && idx, "ball_query_grid: null pointer");
+  GN_REQUIRE(b <= 65535, "ball_query_grid: batch > 65535 unsupported");
+  GridHeader *hdr; int *cs; float *sxyz; int32_t *sidx;
+  grid_carve(const_cast<void *>(grid), b, n, &hdr, &cs, &sxyz, &sidx);
+  dim3 g((m + GQ_WAVES - 1) / GQ_WAVES, b);
+  hipLaunchKernelGGL(ball_grid_kernel, g, dim3(GQ_WAVES * 64), 0, as_stream(stream), new_xyz, hdr, cs, sxyz, sidx, n, m,
+                     radius, nsample, idx);
+  GN_CHECK_LAUNCH("ball_query_grid");
+  return GN_OK;
+}
+
+extern "C" int gn_cylinder_query_unique_grid(const float *new_xyz, const float *rot, const void *grid, int b, int n,
+                                             int m, float radius, float hmin, const float *hmax_host, int ndepth,
+                                             int nsample, int32_t *uidx, int32_t *ucount, gn_stream_t stream) {
+  GN_REQUIRE(b >= 0 && n >= 1 && m >= 0 && nsample >= 1 && nsample <= 64, "cylinder_query_unique_grid: bad sizes");
+  if (b == 0 || m == 0) return GN_OK;
+  GN_REQUIRE(new_xyz && rot && grid && uidx && ucount && hmax_host, "cylinder_query_unique_grid: null pointer");
+  GN_REQUIRE(ndepth == 4, "cylinder_query_unique_grid: only 4 depths supported (got %d)", ndepth);
+  GN_REQUIRE(b <= 65535, "cylinder_query_unique_grid: batch > 65535 unsupported");
+  GN_REQUIRE(n < (1 << 28), "cylinder_query_unique_grid: n must be < 2^28");
+  for (int d = 1; d < 4; ++d)
+    GN_REQUIRE(hmax_host[d] >= hmax_host[d - 1], "cylinder_query_unique_grid: hmax_list must be ascending");
+  GridHeader *hdr; int *cs; float *sxyz; int32_t *sidx;
+  grid_carve(const_cast<void *>(grid), b, n, &hdr, &cs, &sxyz, &sidx);
+  // every hit lies within this distance of the seed: radial <= radius, axial in (hmin, hmax]
+  const float ax = fmaxf(fabsf(hmin), fabsf(hmax_host[3]));
+  const float reach = sqrtf(radius * radius + ax * ax) * 1.0001f;
+  dim3 g((m + GQ_WAVES - 1) / GQ_WAVES, b);
+  hipLaunchKernelGGL((cylinder_unique_grid_kernel<4>), g, dim3(GQ_WAVES * 64), 0, as_stream(stream), new_xyz, rot, hdr,
+                     cs, sxyz, sidx, n, m, radius, hmin, hmax_host[0], hmax_host[1], hmax_host[2], hmax_host[3], reach,
+                     nsample, uidx, ucount);
+  GN_CHECK_LAUNCH("cylinder_query_unique_grid");
+  return GN_OK;
+}

@@ -38,16 +38,16 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int MLP_THREADS = 256;  // 4 waves, one per SIMD
 
 __host__ __device__ constexpr int lds_stride(int c) { return c + 4; }
-__host__ __device__ constexpr int wn_for(int coutp) { return (coutp / 32) >= 4 ? 4 : (coutp / 32); }
+__host__ __device__ constexpr int wn_for(int coutp, int nwv = 4) { return (coutp / 32) >= nwv ? nwv : (coutp / 32); }
 __host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 // ---- one layer's weight slice of this wave, resident in registers
-template <int CINP, int COUTP>
+template <int CINP, int COUTP, int NWV = 4>
 struct LayerW {
   static_assert(CINP % 8 == 0 && COUTP % 32 == 0, "pad CIN to 8 and COUT to 32");
   static constexpr int NT = COUTP / 32;
-  static constexpr int WN = wn_for(COUTP);
-  static constexpr int WM = 4 / WN;
+  static constexpr int WN = wn_for(COUTP, NWV);
+  static constexpr int WM = NWV / WN;
   static_assert(NT % WN == 0, "N tiles must divide over the waves");
   static constexpr int NTW = NT / WN;
   static constexpr int KB = CINP / 8;
@@ -198,10 +198,10 @@ struct PoolMasked {
 };
 
 // ---- one layer over a TP-position LDS tile, weights resident --------------------------------
-template <int TP, int CINP, int COUTP, class Epi>
-__device__ __forceinline__ void run_layer(const LayerW<CINP, COUTP> &w, const float *__restrict__ xs, int wave,
+template <int TP, int CINP, int COUTP, class Epi, int NWV = 4>
+__device__ __forceinline__ void run_layer(const LayerW<CINP, COUTP, NWV> &w, const float *__restrict__ xs, int wave,
                                           int lane, Epi &epi, int mt_count = TP / 32) {
-  using LW = LayerW<CINP, COUTP>;
+  using LW = LayerW<CINP, COUTP, NWV>;
   constexpr int XS = lds_stride(CINP);
   const int wm = wave / LW::WN;
   const int wn = wave % LW::WN;

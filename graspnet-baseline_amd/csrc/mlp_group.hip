@@ -275,15 +275,15 @@ __global__ __launch_bounds__(MLP_THREADS) void sa_hoist_kernel(const float *__re
 // sequence of <=128-row chunks, and the NEXT chunk's rows (index -> xyz gather -> rotate) are
 // fetched into registers while the current chunk runs through the three layers, then dropped into
 // the other half of a double-buffered LDS input tile.
-template <int C1, int C2, int C3, int ND, int CAP>
-__global__ __launch_bounds__(MLP_THREADS) void crop_unique_mlp_kernel(const float *__restrict__ xyz, int n,
+template <int C1, int C2, int C3, int ND, int CAP, int TP, int MINW>
+__global__ __launch_bounds__(MLP_THREADS, MINW) void crop_unique_mlp_kernel(const float *__restrict__ xyz, int n,
                                                                       const float *__restrict__ seed,
                                                                       const float *__restrict__ rot,
                                                                       const int32_t *__restrict__ uidx,
                                                                       const int32_t *__restrict__ ucount, int m,
                                                                       int nseeds, int spb, Mlp3Weights W,
                                                                       float *__restrict__ out) {
-  constexpr int CIN0 = 8, TP = 128, XS0 = lds_stride(CIN0);
+  constexpr int CIN0 = 8, XS0 = lds_stride(CIN0);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *bufY2 = smem;                                  // [TP][C2+4]
   float *bufY1 = bufY2 + TP * lds_stride(C2);           // [TP][C1+4]
@@ -364,6 +364,109 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_unique_mlp_kernel(const floa
     run_layer<TP, C1, C2>(w2, bufY1, wave, lane, e2, mtc);
     __syncthreads();
     run_layer<TP, C2, C3>(w3, bufY2, wave, lane, pool, mtc);
+    if (seed_done) {
+      pool.finish(out + (size_t)sf * ND * C3, C3, (wave % L3::WN) * L3::NTW);
+      pool.reset();
+    }
+    if (!has_next) break;
+    if (tid < TP) put(buf ^ 1, tid, nv, ng);
+    __syncthreads();   // next input tile visible; Y1/Y2 free
+    buf ^= 1;
+    sf = nsf; row0 = nrow0; nu = nnu;
+  }
+}
+
+// 8-wave flavour: two waves per SIMD, each owning half as many output channels (100 weight registers
+// instead of 164), so one wave's LDS / pooling epilogue runs under the other's MFMAs.
+template <int C1, int C2, int C3, int ND, int CAP, int TP>
+__global__ __launch_bounds__(512) void crop_unique8_mlp_kernel(const float *__restrict__ xyz, int n,
+                                                                      const float *__restrict__ seed,
+                                                                      const float *__restrict__ rot,
+                                                                      const int32_t *__restrict__ uidx,
+                                                                      const int32_t *__restrict__ ucount, int m,
+                                                                      int nseeds, int spb, Mlp3Weights W,
+                                                                      float *__restrict__ out) {
+  constexpr int CIN0 = 8, XS0 = lds_stride(CIN0);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *bufY2 = smem;                                  // [TP][C2+4]
+  float *bufY1 = bufY2 + TP * lds_stride(C2);           // [TP][C1+4]
+  float *bufX = bufY1 + TP * lds_stride(C1);            // 2 x [TP][12]
+  float *bufG = bufX + 2 * TP * XS0;                    // 2 x [TP][4] pooling gates
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  LayerW<CIN0, C1, 8> w1;
+  LayerW<C1, C2, 8> w2;
+  LayerW<C2, C3, 8> w3;
+  w1.load(W.w1, W.b1, wave, lane);
+  w2.load(W.w2, W.b2, wave, lane);
+  w3.load(W.w3, W.b3, wave, lane);
+  using L3 = LayerW<C2, C3, 8>;
+  PoolMasked<ND, L3::NTW> pool{bufG, lane, {}};
+  pool.reset();
+
+  const int s_end = min(nseeds, (int)(blockIdx.x + 1) * spb);
+  // chunk cursor: seed sf, first row row0, seed's entry count nu
+  int sf = blockIdx.x * spb;
+  if (sf >= s_end) return;
+  int nu = ucount[sf], row0 = 0;
+
+  // row p of the chunk (sf,row0): gather + rotate; returns the LDS row and its gates
+  auto fetch = [&](int csf, int crow0, int cnu, int p, f32x4 &v, f32x4 &g) {
+    v = f32x4{0.f, 0.f, 0.f, 0.f};
+    g = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (crow0 + p < cnu) {
+      const int e = uidx[(size_t)csf * CAP + crow0 + p];
+      const int src = e & 0x0fffffff;
+      const unsigned mk = (unsigned)e >> 28;
+      const float *c = seed + (size_t)csf * 3;
+      const float *r = rot + (size_t)csf * 9;
+      const float *px = xyz + (size_t)(csf / m) * n * 3;
+      const float x = px[src * 3 + 0] - c[0];
+      const float y = px[src * 3 + 1] - c[1];
+      const float z = px[src * 3 + 2] - c[2];
+      v[0] = x * r[0] + y * r[3] + z * r[6];   // (p-c)^T R, pointnet2_utils.py:528-530
+      v[1] = x * r[1] + y * r[4] + z * r[7];
+      v[2] = x * r[2] + y * r[5] + z * r[8];
+#pragma unroll
+      for (int d = 0; d < ND; ++d) g[d] = ((mk >> d) & 1u) ? 0.f : -INFINITY;
+    }
+  };
+  auto put = [&](int buf, int p, const f32x4 &v, const f32x4 &g) {
+    float *x = bufX + buf * TP * XS0 + p * XS0;
+    *reinterpret_cast<f32x4 *>(x) = v;
+    *reinterpret_cast<f32x4 *>(x + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4 *>(bufG + buf * TP * 4 + p * 4) = g;
+  };
+
+  int buf = 0;
+  {
+    f32x4 v, g;
+    if (tid < TP) { fetch(sf, row0, nu, tid, v, g); put(0, tid, v, g); }
+  }
+  __syncthreads();
+  while (true) {
+    const int rows = min(TP, nu - row0);
+    const int mtc = (rows + 31) >> 5;
+    const bool seed_done = row0 + TP >= nu;
+    // next chunk
+    int nsf = sf, nrow0 = row0 + TP, nnu = nu;
+    if (seed_done) {
+      nsf = sf + 1;
+      nrow0 = 0;
+      nnu = nsf < s_end ? ucount[nsf] : 0;
+    }
+    const bool has_next = nsf < s_end;
+    f32x4 nv, ng;
+    if (has_next && tid < TP) fetch(nsf, nrow0, nnu, tid, nv, ng);   // in flight during the layers below
+
+    pool.sgate = bufG + buf * TP * 4;
+    StoreLds<true> e1{bufY1, lds_stride(C1), C1, lane};
+    run_layer<TP, CIN0, C1, StoreLds<true>, 8>(w1, bufX + buf * TP * XS0, wave, lane, e1, mtc);
+    __syncthreads();
+    StoreLds<true> e2{bufY2, lds_stride(C2), C2, lane};
+    run_layer<TP, C1, C2, StoreLds<true>, 8>(w2, bufY1, wave, lane, e2, mtc);
+    __syncthreads();
+    run_layer<TP, C2, C3, PoolMasked<ND, L3::NTW>, 8>(w3, bufY2, wave, lane, pool, mtc);
     if (seed_done) {
       pool.finish(out + (size_t)sf * ND * C3, C3, (wave % L3::WN) * L3::NTW);
       pool.reset();
@@ -496,16 +599,26 @@ extern "C" int gn_crop_unique_mlp_pool(const float *xyz, const float *seed_xyz, 
     return GN_ERR_INVALID_ARG;
   }
   const Mlp3Weights W{wpacked[0], bias[0], wpacked[1], bias[1], wpacked[2], bias[2]};
-  constexpr int TP = 128;
-  constexpr size_t lds = sizeof(float) * (TP * lds_stride(128) + TP * lds_stride(64) + 2 * TP * lds_stride(8) + 2 * TP * 4);
-  auto k = crop_unique_mlp_kernel<64, 128, 256, 4, 256>;
-  int rc = set_lds(k, lds, "crop_unique_mlp_pool");
-  if (rc) return rc;
+  static const int variant = []() { const char *e = getenv("GN_CROP_VARIANT"); return e ? atoi(e) : 0; }();
   const int nseeds = b * m;
   int spb = nseeds / 2048;   // >= ~8 workgroups per CU in the grid; weights amortised over spb seeds
   spb = spb < 1 ? 1 : (spb > 8 ? 8 : spb);
-  hipLaunchKernelGGL(k, dim3((nseeds + spb - 1) / spb), dim3(MLP_THREADS), lds, as_stream(stream), xyz, n, seed_xyz,
-                     rot, uidx, ucount, m, nseeds, spb, W, out);
+  int rc;
+  if (variant == 1) {        // 8 waves per workgroup (two per SIMD)
+    constexpr int TP = 128;
+    constexpr size_t lds = sizeof(float) * (TP * lds_stride(128) + TP * lds_stride(64) + 2 * TP * lds_stride(8) + 2 * TP * 4);
+    auto k = crop_unique8_mlp_kernel<64, 128, 256, 4, 256, TP>;
+    if ((rc = set_lds(k, lds, "crop_unique_mlp_pool"))) return rc;
+    hipLaunchKernelGGL(k, dim3((nseeds + spb - 1) / spb), dim3(512), lds, as_stream(stream), xyz, n, seed_xyz,
+                       rot, uidx, ucount, m, nseeds, spb, W, out);
+  } else {
+    constexpr int TP = 128;
+    constexpr size_t lds = sizeof(float) * (TP * lds_stride(128) + TP * lds_stride(64) + 2 * TP * lds_stride(8) + 2 * TP * 4);
+    auto k = crop_unique_mlp_kernel<64, 128, 256, 4, 256, TP, 1>;
+    if ((rc = set_lds(k, lds, "crop_unique_mlp_pool"))) return rc;
+    hipLaunchKernelGGL(k, dim3((nseeds + spb - 1) / spb), dim3(MLP_THREADS), lds, as_stream(stream), xyz, n, seed_xyz,
+                       rot, uidx, ucount, m, nseeds, spb, W, out);
+  }
   GN_CHECK_LAUNCH("crop_unique_mlp_pool");
   return GN_OK;
 }

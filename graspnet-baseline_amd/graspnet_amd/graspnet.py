@@ -58,6 +58,8 @@ class GraspNet:
         self.crop_unique = os.environ.get("GN_CROP_PATH", "unique") != "lists"
         # SA2-4: layer 1's per-point part hoisted out of the per-neighbour MLP (bit-identical, fewer MFMAs)
         self.sa_hoist = os.environ.get("GN_SA_PATH", "hoist") != "plain"
+        # neighbour queries on the input cloud through a uniform grid (exact) or by brute-force scan
+        self.query_grid = os.environ.get("GN_QUERY_PATH", "grid") != "brute"
 
     def _run(self, name, status_fn):
         """Issue one C-ABI call; when self.timing is a dict, bracket it with events on the launch stream."""
@@ -139,6 +141,12 @@ class GraspNet:
             # SA1's sampler reports whether any arg-max was an exact tie between distinct points; if not, the
             # deeper levels' samplers (which run on FPS-ordered input) are the identity prefix and say so at once
             tie_flag = torch.empty((B,), dtype=i32, device=dev)
+            grid = None
+            if self.query_grid and N >= 4096:
+                # one grid over the input cloud (cells >= SA1's ball radius) serves SA1's ball query and CloudCrop's
+                # cylinder query; it only needs the coordinates, so it is built before anything else
+                grid = torch.empty((lib.gn_grid_workspace_bytes(B, N),), dtype=torch.uint8, device=dev)
+                self._run("grid_build", lambda: lib.gn_grid_build(xyz.data_ptr(), B, N, SA_CFG[0][1], grid.data_ptr(), st))
             for li, (npoint, radius, nsample, c, mlp) in enumerate(SA_CFG):
                 inds = torch.empty((B, npoint), dtype=i32, device=dev)
                 new_xyz = torch.empty((B, npoint, 3), dtype=f32, device=dev)
@@ -148,8 +156,12 @@ class GraspNet:
                                                        new_xyz.data_ptr(), tie_flag.data_ptr() if li == 0 else None,
                                                        tie_flag.data_ptr() if li > 0 else None, st))
                 idx = torch.empty((B, npoint, nsample), dtype=i32, device=dev)
-                self._run("ball_query[%d]" % (li + 1), lambda: lib.gn_ball_query(new_xyz.data_ptr(), lv_xyz.data_ptr(), B, lv_n, npoint, radius, nsample,
-                                          idx.data_ptr(), st))
+                if li == 0 and grid is not None:
+                    self._run("ball_query_grid[1]", lambda: lib.gn_ball_query_grid(
+                        new_xyz.data_ptr(), grid.data_ptr(), B, lv_n, npoint, radius, nsample, idx.data_ptr(), st))
+                else:
+                    self._run("ball_query[%d]" % (li + 1), lambda: lib.gn_ball_query(
+                        new_xyz.data_ptr(), lv_xyz.data_ptr(), B, lv_n, npoint, radius, nsample, idx.data_ptr(), st))
                 out = torch.empty((B, npoint, mlp[2]), dtype=f32, device=dev)
                 if c > 0 and self.sa_hoist:
                     # layer 1's feature part once per point, then gathered as the accumulator seed
@@ -224,9 +236,14 @@ class GraspNet:
                 # the 4 nested cylinders as one de-duplicated row list per seed (exact, ~2.4x fewer MFMAs)
                 uidx = torch.empty((B, M, D * NS), dtype=i32, device=dev)
                 ucount = torch.empty((B, M), dtype=i32, device=dev)
-                self._run("cylinder_query_unique", lambda: lib.gn_cylinder_query_unique(
-                    seed_xyz.data_ptr(), xyz.data_ptr(), top_rot.data_ptr(), B, N, M, self.cylinder_radius, self.hmin,
-                    self.hmax, D, NS, uidx.data_ptr(), ucount.data_ptr(), st))
+                if grid is not None:
+                    self._run("cylinder_query_unique_grid", lambda: lib.gn_cylinder_query_unique_grid(
+                        seed_xyz.data_ptr(), top_rot.data_ptr(), grid.data_ptr(), B, N, M, self.cylinder_radius, self.hmin,
+                        self.hmax, D, NS, uidx.data_ptr(), ucount.data_ptr(), st))
+                else:
+                    self._run("cylinder_query_unique", lambda: lib.gn_cylinder_query_unique(
+                        seed_xyz.data_ptr(), xyz.data_ptr(), top_rot.data_ptr(), B, N, M, self.cylinder_radius, self.hmin,
+                        self.hmax, D, NS, uidx.data_ptr(), ucount.data_ptr(), st))
                 self._run("crop_unique_mlp_pool", lambda: lib.gn_crop_unique_mlp_pool(
                     xyz.data_ptr(), seed_xyz.data_ptr(), top_rot.data_ptr(), uidx.data_ptr(), ucount.data_ptr(), B, N, M,
                     D, NS, _ci(64, 128, 256), pk.wptr, pk.bptr, vp.data_ptr(), st))

@@ -130,6 +130,24 @@ int gn_knn(const float *ref, const float *query, int b, int d, int nr, int nq, i
  *  and CIN to a multiple of 8; bias padded to the same COUT.
  * ------------------------------------------------------------------ */
 
+/* Uniform-grid acceleration of the queries (exact same results as gn_ball_query / the cylinder queries):
+ * gn_grid_build bins each cloud once into cells at least `reach` wide (workspace of
+ * gn_grid_workspace_bytes(B,N) bytes: header, cell starts, cell-sorted coordinates and original indices);
+ * gn_ball_query_grid then tests only the 3x3x3 cells around a centre and keeps the nsample (<= 64)
+ * smallest hit indices in a sorted 64-lane register, so "first nsample hits in index order", padding and
+ * zero rows are those of ball_query_gpu.cu:14-49.  `reach` must be >= radius. */
+size_t gn_grid_workspace_bytes(int b, int n);
+int gn_grid_build(const float *xyz, int b, int n, float reach, void *workspace, gn_stream_t stream);
+int gn_ball_query_grid(const float *new_xyz, const void *grid, int b, int n, int m, float radius, int nsample,
+                       int32_t *idx, gn_stream_t stream);
+
+/* gn_cylinder_query_unique on the grid (any cell size; the kernel widens its cell window to the cylinder's
+ * bounding sphere).  Same entries and masks; entries come grouped by minimum depth rather than in index
+ * order (the consumer max-pools rows, so order is immaterial).  hmax_host must be ascending. */
+int gn_cylinder_query_unique_grid(const float *new_xyz, const float *rot, const void *grid, int b, int n, int m,
+                                  float radius, float hmin, const float *hmax_host, int ndepth, int nsample,
+                                  int32_t *uidx, int32_t *ucount, gn_stream_t stream);
+
 /* CloudCrop's four CylinderQueryAndGroup queries (models/modules.py:103-106,127-130) in one scan:
  * idx (B, M, ndepth, nsample) i32, each depth with the exact semantics of gn_cylinder_query.
  * hmax_host: HOST array of ndepth floats.  ndepth must be 4. */

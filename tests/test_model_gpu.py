@@ -189,6 +189,35 @@ def test_cylinder_unique_reconstructs_the_four_lists(ref):
                 assert len(sel) <= 64 and np.array_equal(want, lists[b, s, d]), (b, s, d)
 
 
+def test_cylinder_unique_grid_equals_scan(ref):
+    """grid-accelerated de-duplicated cylinder query == the index-order scan: same entries, same masks"""
+    rep, _ = ref
+    L = _lib()
+    lib = L.lib()
+    xyz = rep["input_xyz"].cuda()
+    seed = rep["fp2_xyz"].cuda()
+    seed[0, :3] += 5.0              # empty cylinders
+    seed[1, 3:6] -= 0.08            # partly outside the cloud's box
+    rot = rep["grasp_top_view_rot"].reshape(2, 1024, 9).contiguous().cuda()
+    hm = (ctypes.c_float * 4)(0.01, 0.02, 0.03, 0.04)
+    st = torch.cuda.current_stream().cuda_stream
+    u1 = torch.zeros((2, 1024, 256), dtype=torch.int32, device="cuda"); c1 = torch.empty((2, 1024), dtype=torch.int32, device="cuda")
+    u2 = torch.zeros((2, 1024, 256), dtype=torch.int32, device="cuda"); c2 = torch.empty((2, 1024), dtype=torch.int32, device="cuda")
+    L.check(lib.gn_cylinder_query_unique(seed.data_ptr(), xyz.data_ptr(), rot.data_ptr(), 2, 20000, 1024, 0.05, -0.02, hm, 4, 64,
+                                         u1.data_ptr(), c1.data_ptr(), st), "scan")
+    for reach in (0.04, 0.07, 0.011):      # grids finer and coarser than the cylinder's bounding sphere
+        ws = torch.empty((lib.gn_grid_workspace_bytes(2, 20000),), dtype=torch.uint8, device="cuda")
+        L.check(lib.gn_grid_build(xyz.data_ptr(), 2, 20000, reach, ws.data_ptr(), st), "grid")
+        L.check(lib.gn_cylinder_query_unique_grid(seed.data_ptr(), rot.data_ptr(), ws.data_ptr(), 2, 20000, 1024, 0.05, -0.02, hm,
+                                                  4, 64, u2.data_ptr(), c2.data_ptr(), st), "grid query")
+        assert torch.equal(c1, c2), reach
+        a, b = u1.cpu().numpy(), u2.cpu().numpy()
+        n = c1.cpu().numpy()
+        for bi in range(2):
+            for s in range(1024):
+                assert np.array_equal(np.sort(a[bi, s, :n[bi, s]]), np.sort(b[bi, s, :n[bi, s]])), (reach, bi, s)
+
+
 def test_crop_unique_equals_crop_lists(ref, net):
     """masked pooling over unique rows == pooling the four full lists, bit for bit"""
     rep, _ = ref

@@ -89,6 +89,29 @@ def test_ball_query_bit_exact(E, oracle, n, m, r, ns):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("n,m,r,ns,variant", [(20000, 2048, 0.04, 64, "uniform"), (20000, 2048, 0.04, 64, "surface"),
+                                              (50000, 2048, 0.04, 64, "uniform"), (5000, 300, 0.1, 32, "surface"),
+                                              (3000, 100, 0.3, 16, "uniform"), (2048, 64, 5.0, 64, "uniform"),
+                                              (9000, 50, 0.0005, 8, "uniform")])
+def test_ball_query_grid_bit_exact(oracle, n, m, r, ns, variant):
+    """grid-accelerated ball query == reference semantics (first ns hits in index order, padding, zero rows),
+    incl. dense balls (hundreds of hits), a ball that swallows the whole cloud, empty balls and far-away centres"""
+    from graspnet_amd import _lib as L
+    lib = L.lib()
+    x = _cloud(400 + n, 2, n, variant)
+    c = x[:, torch.randperm(n, generator=torch.Generator().manual_seed(n))[:m]].contiguous()
+    c[0, :5] += 3.0            # centres far outside the cloud: no hit
+    c[1, 5:9] -= 0.03          # slightly outside
+    want = oracle.ball_query(c, x, r, ns)
+    xd, cd = x.cuda(), c.cuda()
+    ws = torch.empty((lib.gn_grid_workspace_bytes(2, n),), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    L.check(lib.gn_grid_build(xd.data_ptr(), 2, n, r, ws.data_ptr(), st), "grid_build")
+    got = torch.empty((2, m, ns), dtype=torch.int32, device="cuda")
+    L.check(lib.gn_ball_query_grid(cd.data_ptr(), ws.data_ptr(), 2, n, m, r, ns, got.data_ptr(), st), "ball_query_grid")
+    assert torch.equal(got.cpu(), want)
+
+
 @pytest.mark.parametrize("n,m,hmax", [(20000, 1024, 0.01), (20000, 1024, 0.04), (4096, 100, 0.02), (50000, 256, 0.03)])
 def test_cylinder_query_bit_exact(E, oracle, model_oracle, n, m, hmax):
     x = _cloud(300 + n, 2, n)

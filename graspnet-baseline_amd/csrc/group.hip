@@ -61,54 +61,50 @@ __global__ __launch_bounds__(256) void group_points_grad_kernel(const float *__r
     atomicAdd(grad_points + ((size_t)b * c + l) * n + a, grad_out[((size_t)b * c + l) * ne + e]);
 }
 
-// interpolate_gpu.cu:14-64: one lane per unknown point, serial ascending scan of `known`
-// (order-dependent strict '<' cascade, so the scan order is the reference's).
-// The known set is staged through LDS in tiles so each coordinate is read from HBM once per block.
-constexpr int NN_THREADS = 64;   // small blocks: the scan is a serial chain per lane, so spread lanes over many CUs
-__global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float *__restrict__ unknown,
-                                                       const float *__restrict__ known, int n, int m,
-                                                       float *__restrict__ dist2,
-                                                       int32_t *__restrict__ idx) {
-  constexpr int TILE = 1024;
-  __shared__ float s_known[TILE * 3];
+// interpolate_gpu.cu:14-64.  The reference scans `known` serially per unknown point with a strict '<'
+// cascade, i.e. it returns the three smallest (distance, index) pairs in lexicographic order.  Here one
+// WAVE owns an unknown point: lane l scans known points l, l+64, ... with the same cascade (so its own
+// three candidates are the lexicographically smallest of its subset), then the wave extracts the global
+// three smallest by three rounds of (min distance, then min index) DPP reductions.
+constexpr int NN_WAVES = 4;
+__global__ __launch_bounds__(NN_WAVES * 64) void three_nn_kernel(const float *__restrict__ unknown,
+                                                                 const float *__restrict__ known, int n, int m,
+                                                                 float *__restrict__ dist2,
+                                                                 int32_t *__restrict__ idx) {
   const int b = blockIdx.y;
-  const int j = blockIdx.x * NN_THREADS + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * NN_WAVES + (threadIdx.x >> 6);
+  if (j >= n) return;
   unknown += (size_t)b * n * 3;
   known += (size_t)b * m * 3;
-  const bool live = j < n;
-  const float ux = live ? unknown[j * 3 + 0] : 0.f;
-  const float uy = live ? unknown[j * 3 + 1] : 0.f;
-  const float uz = live ? unknown[j * 3 + 2] : 0.f;
+  const float ux = unknown[j * 3 + 0], uy = unknown[j * 3 + 1], uz = unknown[j * 3 + 2];
   // reference keeps the bests in doubles initialised to 1e40 (interpolate_gpu.cu:33); a float d
   // compares against them exactly like against +inf, and (float)1e40 == +inf on output.
-  float best1 = INFINITY, best2 = INFINITY, best3 = INFINITY;
-  int besti1 = 0, besti2 = 0, besti3 = 0;
-  for (int k0 = 0; k0 < m; k0 += TILE) {
-    const int cnt = min(TILE, m - k0);
-    __syncthreads();
-    for (int i = threadIdx.x; i < cnt * 3; i += NN_THREADS) s_known[i] = known[k0 * 3 + i];
-    __syncthreads();
-    for (int kk = 0; kk < cnt; ++kk) {
-      const float x = s_known[kk * 3 + 0], y = s_known[kk * 3 + 1], z = s_known[kk * 3 + 2];
-      const float d = (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
-      const int k = k0 + kk;
-      if (d < best1) {
-        best3 = best2; besti3 = besti2;
-        best2 = best1; besti2 = besti1;
-        best1 = d;     besti1 = k;
-      } else if (d < best2) {
-        best3 = best2; besti3 = besti2;
-        best2 = d;     besti2 = k;
-      } else if (d < best3) {
-        best3 = d;     besti3 = k;
-      }
-    }
+  float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+  int i1 = 0x7fffffff, i2 = 0x7fffffff, i3 = 0x7fffffff;
+  for (int k = lane; k < m; k += 64) {
+    const float x = known[k * 3 + 0], y = known[k * 3 + 1], z = known[k * 3 + 2];
+    const float d = (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
+    if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k; }
+    else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = k; }
+    else if (d < b3) { b3 = d; i3 = k; }
   }
-  if (live) {
-    float *od = dist2 + ((size_t)b * n + j) * 3;
-    int32_t *oi = idx + ((size_t)b * n + j) * 3;
-    od[0] = best1; od[1] = best2; od[2] = best3;
-    oi[0] = besti1; oi[1] = besti2; oi[2] = besti3;
+  float od[3];
+  int oi[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    // smallest head distance over the wave (distances are >= 0 or +inf: negate for the max reduction)
+    const float dmin = -wave_max(-b1);
+    const int imin = wave_min_i(b1 == dmin ? i1 : 0x7fffffff);
+    od[r] = dmin;
+    oi[r] = imin == 0x7fffffff ? 0 : imin;     // fewer than r+1 finite candidates: reference leaves index 0
+    if (b1 == dmin && i1 == imin) { b1 = b2; i1 = i2; b2 = b3; i2 = i3; b3 = INFINITY; i3 = 0x7fffffff; }
+  }
+  if (lane == 0) {
+    float *o = dist2 + ((size_t)b * n + j) * 3;
+    int32_t *q = idx + ((size_t)b * n + j) * 3;
+    o[0] = od[0]; o[1] = od[1]; o[2] = od[2];
+    q[0] = oi[0]; q[1] = oi[1]; q[2] = oi[2];
   }
 }
 
@@ -226,8 +222,8 @@ extern "C" int gn_three_nn(const float *unknown, const float *known, int b, int 
   GN_COMMON_CHECKS("three_nn", b >= 0 && n >= 0 && m >= 0);
   if (b == 0 || n == 0) return GN_OK;
   GN_REQUIRE(unknown && dist2 && idx && (known || m == 0), "three_nn: null pointer");
-  dim3 grid((n + NN_THREADS - 1) / NN_THREADS, b);
-  hipLaunchKernelGGL(three_nn_kernel, grid, dim3(NN_THREADS), 0, as_stream(stream), unknown, known, n, m, dist2, idx);
+  dim3 grid((n + NN_WAVES - 1) / NN_WAVES, b);
+  hipLaunchKernelGGL(three_nn_kernel, grid, dim3(NN_WAVES * 64), 0, as_stream(stream), unknown, known, n, m, dist2, idx);
   GN_CHECK_LAUNCH("three_nn");
   return GN_OK;
 }

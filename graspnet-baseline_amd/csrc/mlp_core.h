@@ -289,6 +289,9 @@ __device__ __forceinline__ void run_layer_stream(const float *__restrict__ wp, c
   constexpr int MTW = MT / WM;
   constexpr int KB = CINP / 8, KBC = KC / 8;
   const int wm = wave / WN, wn = wave % WN;
+  // the weights are read-only and noalias, so LLVM would hoist their loads above the workgroup barrier
+  // that precedes this layer (and above the previous layers): launder the pointers here to pin them
+  asm volatile("" : "+s"(wp), "+s"(bp));
   f32x16 acc[MTW][NTW];
 #pragma unroll
   for (int i = 0; i < NTW; ++i) {
@@ -298,14 +301,24 @@ __device__ __forceinline__ void run_layer_stream(const float *__restrict__ wp, c
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][i][r] = bv;
   }
-#pragma unroll 1
-  for (int kc = 0; kc < KB; kc += KBC) {
-    f32x4 b[NTW][KBC];
+  // Weight chunks are double-buffered in registers: chunk c+1 is requested from L2 before the MFMAs of
+  // chunk c are issued, and sched_barriers pin that order (the chunk loop is fully unrolled so both
+  // buffers are statically indexed; without the fences hipcc hoists every chunk's loads and spills).
+  constexpr int NCH = KB / KBC;
+  f32x4 bbuf[2][NTW][KBC];
+  auto load_chunk = [&](int c, f32x4 (&dst)[NTW][KBC]) {
 #pragma unroll
     for (int i = 0; i < NTW; ++i)
 #pragma unroll
       for (int kb = 0; kb < KBC; ++kb)
-        b[i][kb] = *reinterpret_cast<const f32x4 *>(wp + ((size_t)((wn * NTW + i) * KB + kc + kb) * 64 + lane) * 4);
+        dst[i][kb] = *reinterpret_cast<const f32x4 *>(wp + ((size_t)((wn * NTW + i) * KB + c * KBC + kb) * 64 + lane) * 4);
+  };
+  load_chunk(0, bbuf[0]);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (c + 1 < NCH) load_chunk(c + 1, bbuf[(c + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    const int kc = c * KBC;
 #pragma unroll
     for (int mi = 0; mi < MTW; ++mi) {
       const int mt = wm * MTW + mi;
@@ -319,7 +332,7 @@ __device__ __forceinline__ void run_layer_stream(const float *__restrict__ wp, c
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int i = 0; i < NTW; ++i)
-            acc[mi][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kb][s], b[i][kb][s], acc[mi][i], 0, 0, 0);
+            acc[mi][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kb][s], bbuf[c & 1][i][kb][s], acc[mi][i], 0, 0, 0);
       if constexpr (KBC > 2) {   // same read-ahead ladder as run_layer
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
@@ -330,6 +343,7 @@ __device__ __forceinline__ void run_layer_stream(const float *__restrict__ wp, c
         __builtin_amdgcn_sched_group_barrier(0x008, 8 * NTW, 0);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int mi = 0; mi < MTW; ++mi)

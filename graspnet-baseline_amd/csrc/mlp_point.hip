@@ -165,7 +165,7 @@ extern "C" int gn_fp_interp_mlp(const float *known_feat, const float *skip_feat,
   a.w1 = wpacked[0]; a.b1 = bias[0]; a.w2 = wpacked[1]; a.b2 = bias[1];
   a.known = known_feat; a.skip = skip_feat; a.dist2 = dist2; a.idx3 = idx3; a.n = n; a.m = m;
   a.out = out; a.ldo = 256; a.ncols_out = 256; a.nrows = b * n;
-  return launch_point_mlp<LOAD_FP, 512, 256, 256, 256, 256, 0, 128, 128, 0, 32, true>(a, as_stream(stream),
+  return launch_point_mlp<LOAD_FP, 512, 256, 256, 256, 256, 0, 64, 64, 0, 32, true>(a, as_stream(stream),
                                                                                        "fp_interp_mlp");
 }
 
@@ -182,7 +182,7 @@ extern "C" int gn_approach_mlp(const float *x, int rows, int cin, int nout, cons
   PointMlpArgs a{};
   a.w1 = wpacked[0]; a.b1 = bias[0]; a.w2 = wpacked[1]; a.b2 = bias[1]; a.w3 = wpacked[2]; a.b3 = bias[2];
   a.x = x; a.out = out; a.ldo = 302; a.ncols_out = 302; a.nrows = rows;
-  return launch_point_mlp<LOAD_PLAIN, 256, 256, 256, 384, 320, 384, 128, 64, 80, 64, false>(a, as_stream(stream),
+  return launch_point_mlp<LOAD_PLAIN, 256, 256, 256, 384, 320, 384, 64, 32, 40, 64, false>(a, as_stream(stream),
                                                                                              "approach_mlp");
 }
 
@@ -199,7 +199,7 @@ extern "C" int gn_heads_mlp(const float *x, int rows, int cin, int nout, const f
   PointMlpArgs a{};
   a.w1 = wpacked[0]; a.b1 = bias[0]; a.w2 = wpacked[1]; a.b2 = bias[1]; a.w3 = wpacked[2]; a.b3 = bias[2];
   a.x = x; a.out = out; a.ldo = 48; a.ncols_out = 48; a.nrows = rows;
-  return launch_point_mlp<LOAD_PLAIN, 256, 256, 256, 256, 256, 64, 128, 128, 128, 64, false>(a, as_stream(stream),
+  return launch_point_mlp<LOAD_PLAIN, 256, 256, 256, 256, 256, 64, 64, 64, 64, 64, false>(a, as_stream(stream),
                                                                                             "heads_mlp");
 }
 
@@ -212,11 +212,11 @@ extern "C" int gn_point_linear(const float *x, int rows, int cin, int cout, cons
   constexpr int TP = 64;
   hipStream_t s = as_stream(stream);
   if (cin == 128 && cout == 128) {
-    auto k = point_linear_kernel<128, 128, 128, TP>;
+    auto k = point_linear_kernel<128, 128, 64, TP>;
     constexpr size_t lds = sizeof(float) * TP * lds_stride(128);
     hipLaunchKernelGGL(k, dim3((rows + TP - 1) / TP), dim3(MLP_THREADS), lds, s, x, wpacked, bias, rows, out);
   } else if (cin == 256 && cout == 128) {
-    auto k = point_linear_kernel<256, 128, 128, TP>;
+    auto k = point_linear_kernel<256, 128, 64, TP>;
     constexpr size_t lds = sizeof(float) * TP * lds_stride(256);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess) {

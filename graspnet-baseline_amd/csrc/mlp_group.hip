@@ -170,6 +170,76 @@ __global__ __launch_bounds__(MLP_THREADS, MINW) void crop_mlp_kernel(const float
   }
 }
 
+// ---- set abstraction level 1 (coordinates only): sa_mlp_kernel<0,...> with the next tile's rows
+// (index -> xyz gather, centre, /radius) prefetched into registers under the current tile's MFMAs and a
+// double-buffered 6 KB input tile.
+template <int C1, int C2, int C3, int NS>
+__global__ __launch_bounds__(MLP_THREADS) void sa_xyz_kernel(const float *__restrict__ xyz, int n,
+                                                             const float *__restrict__ new_xyz,
+                                                             const int32_t *__restrict__ idx, int np, int ntiles,
+                                                             int tpb, float radius, Mlp3Weights W,
+                                                             float *__restrict__ out) {
+  constexpr int TP = 128, GPT = TP / NS, XS0 = lds_stride(8);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *bufY1 = smem;                          // [TP][C1+4]
+  float *bufY2 = bufY1 + TP * lds_stride(C1);   // [TP][C2+4]
+  float *bufX = bufY2 + TP * lds_stride(C2);    // 2 x [TP][12]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  LayerW<8, C1> w1;
+  LayerW<C1, C2> w2;
+  LayerW<C2, C3> w3;
+  w1.load(W.w1, W.b1, wave, lane);
+  w2.load(W.w2, W.b2, wave, lane);
+  w3.load(W.w3, W.b3, wave, lane);
+  const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * tpb);
+  int tile = blockIdx.x * tpb;
+  if (tile >= tile_end) return;
+  auto fetch_x = [&](int tl, f32x4 &v) {
+    const int g0 = tl * GPT;
+    const int b = g0 / np;
+    v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < TP) {
+      const int src = idx[(size_t)g0 * NS + tid];
+      const float *c = new_xyz + ((size_t)g0 + tid / NS) * 3;
+      const float *px = xyz + (size_t)b * n * 3;
+      v[0] = (px[src * 3 + 0] - c[0]) / radius;   // pointnet2_utils.py:346-348
+      v[1] = (px[src * 3 + 1] - c[1]) / radius;
+      v[2] = (px[src * 3 + 2] - c[2]) / radius;
+    }
+  };
+  auto put_x = [&](int buf, const f32x4 &v) {
+    if (tid < TP) {
+      float *x = bufX + buf * TP * XS0 + tid * XS0;
+      *reinterpret_cast<f32x4 *>(x) = v;
+      *reinterpret_cast<f32x4 *>(x + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  int buf = 0;
+  {
+    f32x4 v;
+    fetch_x(tile, v);
+    put_x(0, v);
+  }
+  __syncthreads();
+  for (; tile < tile_end; ++tile) {
+    const int g0 = tile * GPT;
+    const bool has_next = tile + 1 < tile_end;
+    f32x4 nv;
+    if (has_next) fetch_x(tile + 1, nv);          // in flight under the three layers
+    StoreLds<true> e1{bufY1, lds_stride(C1), C1, lane};
+    run_layer<TP, 8, C1>(w1, bufX + buf * TP * XS0, wave, lane, e1);
+    __syncthreads();
+    StoreLds<true> e2{bufY2, lds_stride(C2), C2, lane};
+    run_layer<TP, C1, C2>(w2, bufY1, wave, lane, e2);
+    __syncthreads();
+    PoolGlobal<NS, LayerW<C2, C3>::NTW> e3{out + (size_t)g0 * C3, C3, lane, {}};
+    run_layer<TP, C2, C3>(w3, bufY2, wave, lane, e3);
+    if (has_next) put_x(buf ^ 1, nv);
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
 // ---- set abstraction with layer 1 hoisted (levels with input features) ---------------------------
 // Layer 1 of a grouped MLP is  W1f * feat_j + W1x * (x_j - c_i)/r + b.  The first term does not depend
 // on the group, yet the reference (and sa_mlp_kernel) recompute it for each of the ~16 groups a
@@ -536,8 +606,20 @@ extern "C" int gn_sa_group_mlp_pool(const float *xyz, const float *feat, const f
   hipStream_t s = as_stream(stream);
   const int c1 = mlp[0], c2 = mlp[1], c3 = mlp[2];
   // configurations of models/backbone.py:30-64
-  if (c == 0 && c1 == 64 && c2 == 64 && c3 == 128 && ns == 64)
-    return launch_sa<0, 64, 64, 128, 64, 128>(xyz, feat, new_xyz, idx, b, n, np, radius, W, out, s);
+  if (c == 0 && c1 == 64 && c2 == 64 && c3 == 128 && ns == 64) {
+    constexpr int TP = 128;
+    GN_REQUIRE(np % (TP / 64) == 0, "sa_group_mlp_pool: npoint must be even");
+    const int ntiles = (int)((long)b * np / (TP / 64));
+    constexpr size_t lds = sizeof(float) * (TP * lds_stride(64) + TP * lds_stride(64) + 2 * TP * lds_stride(8));
+    auto k = sa_xyz_kernel<64, 64, 128, 64>;
+    int rc = set_lds(k, lds, "sa_group_mlp_pool");
+    if (rc) return rc;
+    const int tpb = tiles_per_block(ntiles);
+    hipLaunchKernelGGL(k, dim3((ntiles + tpb - 1) / tpb), dim3(MLP_THREADS), lds, s, xyz, n, new_xyz, idx, np, ntiles,
+                       tpb, radius, W, out);
+    GN_CHECK_LAUNCH("sa_group_mlp_pool");
+    return GN_OK;
+  }
   if (c == 128 && c1 == 128 && c2 == 128 && c3 == 256 && ns == 32)
     return launch_sa<128, 128, 128, 256, 32, 128>(xyz, feat, new_xyz, idx, b, n, np, radius, W, out, s);
   if (c == 256 && c1 == 128 && c2 == 128 && c3 == 256 && ns == 16)

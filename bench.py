@@ -18,10 +18,11 @@ import os
 import sys
 import time
 
-# ROCm maps HIP streams onto this many hardware queues (default 4).  The bench overlaps up to 6
-# batches (FPS is a serial chain on 8 CUs per batch); with 4 queues two batches share a queue and
-# serialise.  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# ROCm maps HIP streams onto this many hardware queues (default 4).  The bench overlaps up to 8
+# batches (FPS is a serial chain on 8 CUs per batch); with too few queues two batches share a queue
+# and serialise (measured, 200 steps: 4 queues/3 streams 2050, 8/6 3900, 16/8 4150 scenes/s).
+# Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "graspnet-baseline_amd")):
@@ -94,11 +95,11 @@ def op_rooflines(dev, reps=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--batch", type=int, default=8, help="scenes per GPU per step")
     ap.add_argument("--points", type=int, default=20000)
-    ap.add_argument("--streams", type=int, default=6,
+    ap.add_argument("--streams", type=int, default=8,
                     help="HIP streams the steps are issued round-robin on (FPS is a serial chain on 8 CUs per "
                          "batch; other batches' kernels fill the rest of the chip meanwhile)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

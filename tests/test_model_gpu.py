@@ -373,6 +373,38 @@ def test_graph_captured_forward_matches_eager(net, clouds):
     assert torch.equal(c2, c0.flip(0)) and torch.equal(g2, g0.flip(0))
 
 
+@pytest.mark.parametrize("B,N,variant", [(1, 3000, "uniform"), (3, 4096, "surface"), (2, 9000, "uniform"),
+                                         (1, 12289, "surface"), (2, 16384, "uniform"), (1, 24000, "uniform"),
+                                         (1, 30000, "surface")])
+def test_other_batch_and_cloud_sizes(net, model_oracle, state_dict, B, N, variant):
+    """every kernel-selection branch (register / region / tiered FPS, grid vs scan queries, ragged batches) against
+    the oracle: sampling indices and coordinates bit-exact, features and grasp rows within tolerance"""
+    from graspnet_amd import pred_decode, synthetic as S
+    cl = S.make_batch(500 + N, B, N, variant)
+    rep = model_oracle.forward({"point_clouds": cl.clone()}, state_dict)
+    rp = model_oracle.pred_decode(rep)
+    ep = net({"point_clouds": cl.cuda()})
+    pr = pred_decode(ep)
+    for k in ("sa1_inds", "sa2_inds", "fp2_inds", "sa1_xyz", "sa2_xyz", "sa3_xyz", "sa4_xyz"):
+        assert torch.equal(ep[k].cpu(), rep[k]), k
+    for k in ("sa1_features", "fp2_features", "view_score", "objectness_score"):
+        d = (ep[k].cpu() - rep[k]).abs().max().item()
+        assert d < 5e-4, (k, d)
+    flips = (ep["grasp_top_view_inds"].cpu() != rep["grasp_top_view_inds"]).sum().item()
+    assert flips <= 4
+    for a, r in zip(pr, rp):
+        assert abs(a.shape[0] - r.shape[0]) <= 3
+        ka = {tuple(x[13:16].tolist()): x for x in a.cpu()}
+        kr = {tuple(x[13:16].tolist()): x for x in r}
+        same = [k for k in ka if k in kr and torch.allclose(ka[k][3:13], kr[k][3:13], atol=1e-5)]
+        assert len(same) >= 0.97 * len(kr)
+        # the decoded score is score * tolerance / 0.05 (graspnet.py:121): a product of two fp32 network outputs
+        # times 20, so it amplifies their ~1e-5 differences; on these off-design clouds (sparse, large activations)
+        # both fp32 paths sit ~1e-4 from float64, hence 3e-4 here (the headline configuration is held to 1e-4 above)
+        for k in same:
+            assert abs(float(ka[k][0] - kr[k][0])) <= 3e-4 + 3e-4 * abs(float(kr[k][0])), (k, float(ka[k][0]), float(kr[k][0]))
+
+
 def test_refuses_cpu_and_training(state_dict):
     from graspnet_amd import GraspNet
     with pytest.raises(NotImplementedError):

@@ -87,3 +87,25 @@ def test_ops_regression_vectors(oracle, golden_dir):
         d2, ti = oracle.three_nn(x[:, :200].contiguous(), nx)
         assert np.array_equal(ti.numpy(), z[name + "/nn_idx"])
         assert np.array_equal(d2.numpy(), z[name + "/nn_d2"])
+
+
+def test_example_scene_fixture(model_oracle, state_dict, golden_dir):
+    """doc/example_data scene (cloud made by the reference's create_point_cloud_from_depth_image): the oracle
+    pipeline reproduces the committed rows; depth_to_cloud restatement reproduces the cloud from the stored pixels."""
+    from oracle import post_oracle as PO
+    z = np.load(golden_dir + "/example_scene_n20000.npz")
+    h, w = int(z["shape"][0]), int(z["shape"][1])
+    fx, fy, cx, cy, factor = [float(v) for v in z["intrinsics"]]
+    depth = np.zeros(h * w, np.uint16)
+    depth[z["pix"]] = z["depth_at_pix"]
+    cloud = PO.depth_to_cloud(depth.reshape(h, w), fx, fy, cx, cy, factor)[z["pix"]].astype(np.float32)
+    assert np.array_equal(cloud, z["cloud"])
+    ep = model_oracle.forward({"point_clouds": torch.from_numpy(cloud).unsqueeze(0)}, state_dict)
+    assert np.array_equal(ep["sa1_inds"].numpy(), z["sa1_inds"])
+    g = model_oracle.pred_decode(ep)[0].numpy()
+    assert g.shape == z["grasps"].shape
+    np.testing.assert_allclose(g, z["grasps"], rtol=1e-4, atol=1e-4)
+    scene = PO.voxel_down_sample(cloud, 0.01)
+    assert len(scene) == int(z["n_scene_voxels"][0])
+    cm, _, _ = PO.collision_detect(scene, z["grasps"], approach_dist=0.05, collision_thresh=0.01, voxel_size=0.01)
+    assert np.array_equal(cm, z["collision_mask"])

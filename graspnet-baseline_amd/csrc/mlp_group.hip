@@ -643,7 +643,6 @@ extern "C" int gn_crop_group_mlp_pool(const float *xyz, const float *seed_xyz, c
   }
   constexpr int NS = 64, ND = 4;
   const Mlp3Weights W{wpacked[0], bias[0], wpacked[1], bias[1], wpacked[2], bias[2]};
-  static const int variant = []() { const char *e = getenv("GN_CROP_VARIANT"); return e ? atoi(e) : 0; }();
   auto launch = [&](auto kernel, int tp, size_t lds) -> int {
     if ((m * ND) % (tp / NS) != 0) { set_error("crop_group_mlp_pool: bad seed count"); return GN_ERR_INVALID_ARG; }
     const int ntiles = (int)((long)b * m * ND / (tp / NS));
@@ -654,13 +653,8 @@ extern "C" int gn_crop_group_mlp_pool(const float *xyz, const float *seed_xyz, c
                        seed_xyz, rot, idx, m, ntiles, tpb, W, out);
     return GN_OK;
   };
-  int rc;
-  if (variant == 1)
-    rc = launch(crop_mlp_kernel<64, 128, 256, NS, ND, 64, 2, false>, 64,
-                sizeof(float) * group_mlp_lds_floats<8, 64, 128, 64>());
-  else
-    rc = launch(crop_mlp_kernel<64, 128, 256, NS, ND, 128, 1, true>, 128,
-                sizeof(float) * group_mlp_lds_floats<8, 64, 128, 128>());
+  int rc = launch(crop_mlp_kernel<64, 128, 256, NS, ND, 128, 1, true>, 128,
+                  sizeof(float) * group_mlp_lds_floats<8, 64, 128, 128>());
   if (rc) return rc;
   GN_CHECK_LAUNCH("crop_group_mlp_pool");
   return GN_OK;
@@ -681,12 +675,12 @@ extern "C" int gn_crop_unique_mlp_pool(const float *xyz, const float *seed_xyz, 
     return GN_ERR_INVALID_ARG;
   }
   const Mlp3Weights W{wpacked[0], bias[0], wpacked[1], bias[1], wpacked[2], bias[2]};
-  static const int variant = []() { const char *e = getenv("GN_CROP_VARIANT"); return e ? atoi(e) : 0; }();
+  static const int variant = []() { const char *e = getenv("GN_CROP_VARIANT"); return e ? atoi(e) : 1; }();
   const int nseeds = b * m;
   int spb = nseeds / 2048;   // >= ~8 workgroups per CU in the grid; weights amortised over spb seeds
   spb = spb < 1 ? 1 : (spb > 8 ? 8 : spb);
   int rc;
-  if (variant == 1) {        // 8 waves per workgroup (two per SIMD)
+  if (variant == 1) {        // default: 8 waves per workgroup (two per SIMD), 2-4 % faster end to end
     constexpr int TP = 128;
     constexpr size_t lds = sizeof(float) * (TP * lds_stride(128) + TP * lds_stride(64) + 2 * TP * lds_stride(8) + 2 * TP * 4);
     auto k = crop_unique8_mlp_kernel<64, 128, 256, 4, 256, TP>;

@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--batch", type=int, default=8, help="scenes per GPU per step")
     ap.add_argument("--points", type=int, default=20000)
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: a fixed global batch cut into contiguous per-rank shards "
+                         "(default 0 = weak scaling, --batch scenes on every rank)")
     ap.add_argument("--streams", type=int, default=8,
                     help="HIP streams the steps are issued round-robin on (FPS is a serial chain on 8 CUs per "
                          "batch; other batches' kernels fill the rest of the chip meanwhile)")
@@ -122,8 +125,15 @@ def main():
     from graspnet_amd import dist as gdist
     B, N = args.batch, args.points
     net = GraspNet(is_training=False, device=dev).load_state_dict(S.make_state_dict(0))
-    # weak scaling: every rank owns its own B scenes (global batch = world*B, contiguous shards)
-    lo, _ = gdist.shard_range(world * B, rank, world)
+    # weak scaling: every rank owns its own B scenes (global batch = world*B, contiguous shards);
+    # strong scaling (--global-batch G): the same G scenes however many ranks share them
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit("--global-batch must be a multiple of the number of ranks (equal shards for the all-gather)")
+        lo, hi = gdist.shard_range(args.global_batch, rank, world)
+        B = hi - lo
+    else:
+        lo, _ = gdist.shard_range(world * B, rank, world)
     clouds = S.make_batch(1000 + lo, B, N, "uniform").to(dev)
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
@@ -204,7 +214,7 @@ def main():
             "metric": "scenes/s grasp inference, 20k-pt clouds, batch 8",
             "value": world * B * args.steps / elapsed, "unit": "scenes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "config[1]: batch %d x %d-pt synthetic clouds per GPU, full SA->ApproachNet->"
                                    "CloudCrop->OperationNet/ToleranceNet->pred_decode, seeded random weights" % (B, N),

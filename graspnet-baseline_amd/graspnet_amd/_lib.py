@@ -17,6 +17,28 @@ _lib = None
 
 _c_int, _c_float, _c_void_p, _c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 
+
+
+class MlpWeights(ctypes.Structure):          # gn_mlp_weights
+    _fields_ = [("w", _c_void_p * 3), ("b", _c_void_p * 3)]
+
+
+class Weights(ctypes.Structure):             # gn_weights
+    _fields_ = [("sa", MlpWeights * 4), ("sa_pre", MlpWeights * 4), ("fp", MlpWeights * 2), ("approach", MlpWeights),
+                ("crop", MlpWeights), ("heads", MlpWeights), ("views", _c_void_p), ("view_rot", _c_void_p),
+                ("decode_rot", _c_void_p), ("cylinder_radius", _c_float), ("hmin", _c_float), ("hmax", _c_float * 4)]
+
+
+class Outputs(ctypes.Structure):             # gn_outputs
+    _fields_ = [("sa_inds", _c_void_p * 4), ("sa_xyz", _c_void_p * 4), ("sa_features", _c_void_p * 4),
+                ("fp2_features", _c_void_p), ("approach", _c_void_p), ("top_view_inds", _c_void_p),
+                ("top_view_score", _c_void_p), ("top_view_xyz", _c_void_p), ("top_view_rot", _c_void_p),
+                ("vp_features", _c_void_p), ("head", _c_void_p), ("crop_uidx", _c_void_p), ("crop_ucount", _c_void_p),
+                ("grasps", _c_void_p), ("counts", _c_void_p)]
+
+
+STAGE_HOOK = ctypes.CFUNCTYPE(None, ctypes.c_char_p, _c_int, _c_void_p)   # gn_stage_hook
+
 # name -> (restype, argtypes); must list every symbol include/graspnet_hip.h declares
 SIGNATURES = {
     "gn_last_error": (ctypes.c_char_p, []),
@@ -75,6 +97,9 @@ SIGNATURES = {
     "gn_grasp_nms_workspace_bytes": (_c_size_t, [_c_int]),
     "gn_grasp_nms": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, ctypes.c_double, ctypes.c_double, _c_int,
                               _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "gn_graspnet_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
+    "gn_graspnet_forward": (_c_int, [ctypes.POINTER(Weights), _c_void_p, _c_int, _c_int, _c_void_p, ctypes.POINTER(Outputs),
+                                     STAGE_HOOK, _c_void_p, _c_void_p]),
     "gn_pred_decode": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                 _c_int, _c_void_p, _c_void_p, _c_void_p]),
 }

@@ -60,6 +60,10 @@ class GraspNet:
         self.sa_hoist = os.environ.get("GN_SA_PATH", "hoist") != "plain"
         # neighbour queries on the input cloud through a uniform grid (exact) or by brute-force scan
         self.query_grid = os.environ.get("GN_QUERY_PATH", "grid") != "brute"
+        # the default configuration is sequenced by the library itself (gn_graspnet_forward: one host call per
+        # forward); GN_FORWARD=stages issues the same stage calls one by one from here (always used for the
+        # non-default A/B paths above)
+        self.native_forward = os.environ.get("GN_FORWARD", "native") != "stages"
 
     def _run(self, name, status_fn):
         """Issue one C-ABI call; when self.timing is a dict, bracket it with events on the launch stream."""
@@ -111,6 +115,96 @@ class GraspNet:
         self._packed = weights.prepare(self._sd, self.device, self.num_view, self.num_angle)
         v, vr, dr = geometry.build_tables(self.num_view, self.num_angle)
         self._tables = (v.to(self.device), vr.to(self.device), dr.to(self.device))
+        self._cweights = self._make_cweights()
+
+    def _make_cweights(self):
+        """gn_weights for gn_graspnet_forward (device pointers into self._packed / self._tables)."""
+        w, pk = L.Weights(), self._packed
+
+        def fill(dst, packed):
+            for i, (wt, bt) in enumerate(zip(packed.w, packed.b)):
+                dst.w[i], dst.b[i] = wt.data_ptr(), bt.data_ptr()
+
+        fill(w.sa[0], pk["sa1"])
+        for l in (1, 2, 3):
+            fill(w.sa[l], pk["sa%d_hoist" % (l + 1)])
+            fill(w.sa_pre[l], pk["sa%d_pre" % (l + 1)])
+        fill(w.fp[0], pk["fp1"])
+        fill(w.fp[1], pk["fp2"])
+        fill(w.approach, pk["approach"])
+        fill(w.crop, pk["crop"])
+        fill(w.heads, pk["heads"])
+        w.views, w.view_rot, w.decode_rot = (t.data_ptr() for t in self._tables)
+        w.cylinder_radius, w.hmin = self.cylinder_radius, self.hmin
+        for i in range(4):
+            w.hmax[i] = self.hmax[i]
+        return w
+
+    def _forward_native(self, end_points, xyz):
+        """One gn_graspnet_forward call: outputs allocated here, scratch in one workspace tensor."""
+        lib = L.lib()
+        dev = xyz.device
+        B, N = xyz.size(0), xyz.size(1)
+        f32, i32 = torch.float32, torch.int32
+        M, D, A, nv = SA_CFG[1][0], self.num_depth, self.num_angle, 2 + self.num_view
+
+        def new(shape, dt=f32):
+            return torch.empty(shape, dtype=dt, device=dev)
+
+        o = L.Outputs()
+        inds, xyzs, feats = [], [], []
+        for li, (npoint, _, _, _, mlp) in enumerate(SA_CFG):
+            inds.append(new((B, npoint), i32)); xyzs.append(new((B, npoint, 3))); feats.append(new((B, npoint, mlp[2])))
+            o.sa_inds[li], o.sa_xyz[li], o.sa_features[li] = inds[li].data_ptr(), xyzs[li].data_ptr(), feats[li].data_ptr()
+        seed_feat, feat302 = new((B, M, 256)), new((B, M, nv))
+        top_inds, top_score = new((B, M), torch.int64), new((B, M))
+        top_xyz, top_rot = new((B, M, 3)), new((B, M, 3, 3))
+        vp, head = new((B, M * D, 256)), new((B, M, D, 4 * A))
+        uidx, ucount = new((B, M, D * self.crop_nsample), i32), new((B, M), i32)
+        ws = new((lib.gn_graspnet_workspace_bytes(B, N),), torch.uint8)
+        o.fp2_features, o.approach, o.top_view_inds, o.top_view_score = (
+            seed_feat.data_ptr(), feat302.data_ptr(), top_inds.data_ptr(), top_score.data_ptr())
+        o.top_view_xyz, o.top_view_rot, o.vp_features, o.head = (
+            top_xyz.data_ptr(), top_rot.data_ptr(), vp.data_ptr(), head.data_ptr())
+        o.crop_uidx, o.crop_ucount = uidx.data_ptr(), ucount.data_ptr()
+        o.grasps = o.counts = None
+        hook = _NO_HOOK
+        if self.timing is not None:
+            pending = {}
+
+            def on_stage(name, phase, _user):
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                if phase == 0:
+                    pending[name] = ev
+                else:
+                    self.timing.setdefault(name.decode(), []).append((pending.pop(name), ev))
+            hook = L.STAGE_HOOK(on_stage)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        L.check(lib.gn_graspnet_forward(ctypes.byref(self._cweights), xyz.data_ptr(), B, N, ws.data_ptr(),
+                                        ctypes.byref(o), hook, None, st), "graspnet_forward")
+        for li in range(4):
+            name = "sa%d" % (li + 1)
+            if li < 2:
+                end_points[name + "_inds"] = inds[li]
+            end_points[name + "_xyz"] = xyzs[li]
+            end_points[name + "_features"] = feats[li].transpose(1, 2)
+        end_points["fp2_features"] = seed_feat.transpose(1, 2)
+        end_points["fp2_xyz"] = xyzs[1]
+        end_points["fp2_inds"] = inds[0][:, 0:M]
+        end_points["objectness_score"] = feat302[:, :, 0:2].transpose(1, 2)
+        end_points["view_score"] = feat302[:, :, 2:]
+        end_points["grasp_top_view_inds"] = top_inds
+        end_points["grasp_top_view_score"] = top_score
+        end_points["grasp_top_view_xyz"] = top_xyz
+        end_points["grasp_top_view_rot"] = top_rot
+        hv = head.permute(0, 3, 1, 2)
+        end_points["grasp_score_pred"] = hv[:, 0:A]
+        end_points["grasp_angle_cls_pred"] = hv[:, A:2 * A]
+        end_points["grasp_width_pred"] = hv[:, 2 * A:3 * A]
+        end_points["grasp_tolerance_pred"] = hv[:, 3 * A:4 * A]
+        end_points["_gn"] = {"feat": feat302, "head": head, "model": self, "vp": vp, "uidx": uidx, "ucount": ucount}
+        return end_points
 
     def __call__(self, end_points):
         return self.forward(end_points)
@@ -134,6 +228,8 @@ class GraspNet:
             xyz = pc[..., 0:3].contiguous()                      # backbone.py:69-75 _break_up_pc
             end_points["input_xyz"] = xyz
             end_points["input_features"] = None
+            if self.native_forward and self.crop_unique and self.sa_hoist and self.query_grid and N >= SA_CFG[0][0]:
+                return self._forward_native(end_points, xyz)
 
             # ---- 4 set-abstraction levels (backbone.py:105-121)
             lv_xyz, lv_feat, lv_n, lv_inds = xyz, None, N, []
@@ -326,6 +422,9 @@ class GraphedGraspNet:
         self.static_in.copy_(point_clouds[..., 0:3], non_blocking=True)
         self.graph.replay()
         return self.end_points, self.grasps, self.counts
+
+
+_NO_HOOK = L.STAGE_HOOK()      # NULL function pointer
 
 
 def _expected_keys():

@@ -237,6 +237,58 @@ int gn_pred_decode(const float *feat, int ldf, const float *head, const int64_t 
                    float *grasps, int32_t *counts, gn_stream_t stream);
 
 /* ------------------------------------------------------------------ *
+ *  Whole path in one call (SURVEY.md 8b "fused entry"): what a C/C++ host (e.g. a ROS node) binds
+ *  instead of GraspNet.forward (models/graspnet.py:70-75) + pred_decode (:77-134).  Host-side
+ *  sequencing only: it enqueues the stages above on `stream` (grid queries, hoisted SA tails,
+ *  de-duplicated CloudCrop); nothing allocates or synchronises, so the call is hipGraph-capturable.
+ *  The network constants are those of models/backbone.py:30-64 and models/graspnet.py:31-45
+ *  (2048/1024/512/256 centres, 300 views, 12 angles, 4 depths, 64 crop samples).
+ * ------------------------------------------------------------------ */
+typedef struct gn_mlp_weights {      /* up to 3 packed layers (device pointers), see the layout note above */
+  const float *w[3];
+  const float *b[3];
+} gn_mlp_weights;
+
+typedef struct gn_weights {
+  gn_mlp_weights sa[4];      /* sa[0]: SA1 layers on [xyz | pad]; sa[1..3]: hoisted tails, w[0] = K=8 coordinate block */
+  gn_mlp_weights sa_pre[4];  /* sa_pre[l].w[0]/b[0] (l>=1): layer 1's per-point feature part (gn_point_linear) */
+  gn_mlp_weights fp[2];      /* fp1 (sa4->sa3), fp2 (sa3->sa2): 2 layers each */
+  gn_mlp_weights approach;   /* 256->256->302->302, layer 3 K padded to 320 */
+  gn_mlp_weights crop;       /* 3->64->128->256 */
+  gn_mlp_weights heads;      /* OperationNet+ToleranceNet merged 256->256->256->48 */
+  const float *views;        /* (300,3)  loss_utils.py:41-66 template */
+  const float *view_rot;     /* (300,9)  rotation of each template view, in-plane angle 0 */
+  const float *decode_rot;   /* (300*12,9) rotation of (-view, angle class) used by pred_decode */
+  float cylinder_radius, hmin, hmax[4];
+} gn_weights;
+
+typedef struct gn_outputs {          /* device buffers owned by the caller; all required unless noted */
+  int32_t *sa_inds[4];               /* (B,np_l) np = 2048,1024,512,256 */
+  float *sa_xyz[4];                  /* (B,np_l,3) */
+  float *sa_features[4];             /* (B,np_l,C_l) position-major, C = 128,256,256,256 */
+  float *fp2_features;               /* (B,1024,256) */
+  float *approach;                   /* (B,1024,302) = [objectness(2) | view_score(300)] */
+  int64_t *top_view_inds;            /* (B,1024) */
+  float *top_view_score;             /* (B,1024) */
+  float *top_view_xyz;               /* (B,1024,3) */
+  float *top_view_rot;               /* (B,1024,9) */
+  float *vp_features;                /* (B,1024*4,256) */
+  float *head;                       /* (B,1024,4,48) = [score | angle cls | width | tolerance] x 12 */
+  int32_t *crop_uidx, *crop_ucount;  /* optional (B,1024,256) / (B,1024): the de-duplicated crop lists */
+  float *grasps;                     /* optional (B,1024,17): NULL skips pred_decode */
+  int32_t *counts;                   /* (B), with grasps */
+} gn_outputs;
+
+/* Optional per-launch hook (profiling): called on the host right before (phase 0) and right after
+ * (phase 1) each stage is enqueued. */
+typedef void (*gn_stage_hook)(const char *stage, int phase, void *user);
+
+size_t gn_graspnet_workspace_bytes(int b, int n);
+int gn_graspnet_forward(const gn_weights *weights, const float *cloud /* (B,N,3) */, int b, int n,
+                        void *workspace, const gn_outputs *out, gn_stage_hook hook, void *hook_user,
+                        gn_stream_t stream);
+
+/* ------------------------------------------------------------------ *
  *  Around the network: front end and post-processing   *
  * ------------------------------------------------------------------ */
 

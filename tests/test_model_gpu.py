@@ -356,6 +356,63 @@ def test_fps_prefix_shortcut_and_tie_fallback(net, oracle):
             assert identity
 
 
+@pytest.mark.parametrize("N", [20000, 3000])
+def test_library_sequenced_forward_equals_stage_calls(net, state_dict, clouds, N):
+    """gn_graspnet_forward (one C call for the whole path, include/graspnet_hip.h) issues the same launches as the
+    stage-by-stage host sequence: every end_points tensor and the decoded rows are bit-identical; with
+    grasps/counts given, the call also runs pred_decode itself"""
+    import ctypes
+    from graspnet_amd import GraspNet, _lib as L
+    staged = GraspNet().load_state_dict(state_dict)
+    staged.native_forward = False
+    x = clouds.cuda()[:, :N].contiguous()
+    a = net({"point_clouds": x})
+    b = staged({"point_clouds": x})
+    assert net.native_forward and "workspace" not in b["_gn"]
+    keys = [k for k in b if k not in ("_gn", "input_features", "point_clouds")]
+    assert set(keys) <= set(a)
+    for k in keys:
+        assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype, k
+        assert torch.equal(a[k], b[k]), k
+    ga, ca = net.decode_padded(a)
+    gb, cb = staged.decode_padded(b)
+    assert torch.equal(ga, gb) and torch.equal(ca, cb)
+    for k in ("ucount", "vp"):
+        assert torch.equal(a["_gn"][k], b["_gn"][k]), k
+    valid = torch.arange(256, device="cuda")[None, None, :] < a["_gn"]["ucount"][..., None]   # entries past ucount are unwritten
+    assert torch.equal(a["_gn"]["uidx"][valid], b["_gn"]["uidx"][valid])
+
+    # the raw C call with decode included, the way a C/C++ host would use it
+    lib = L.lib()
+    B = x.shape[0]
+    o = L.Outputs()
+    keep = []
+
+    def buf(shape, dt=torch.float32):
+        t = torch.empty(shape, dtype=dt, device="cuda"); keep.append(t); return t.data_ptr()
+    for li, (npnt, c) in enumerate(((2048, 128), (1024, 256), (512, 256), (256, 256))):
+        o.sa_inds[li], o.sa_xyz[li], o.sa_features[li] = buf((B, npnt), torch.int32), buf((B, npnt, 3)), buf((B, npnt, c))
+    o.fp2_features, o.approach = buf((B, 1024, 256)), buf((B, 1024, 302))
+    o.top_view_inds, o.top_view_score = buf((B, 1024), torch.int64), buf((B, 1024))
+    o.top_view_xyz, o.top_view_rot = buf((B, 1024, 3)), buf((B, 1024, 9))
+    o.vp_features, o.head = buf((B, 4096, 256)), buf((B, 1024, 4, 48))
+    grasps = torch.empty((B, 1024, 17), device="cuda"); counts = torch.empty((B,), dtype=torch.int32, device="cuda")
+    o.grasps, o.counts = grasps.data_ptr(), counts.data_ptr()
+    ws = torch.empty((lib.gn_graspnet_workspace_bytes(B, N),), dtype=torch.uint8, device="cuda")
+    rc = lib.gn_graspnet_forward(ctypes.byref(net._cweights), x.data_ptr(), B, N, ws.data_ptr(), ctypes.byref(o),
+                                 L.STAGE_HOOK(), None, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.gn_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(grasps, ga) and torch.equal(counts, ca)
+    # argument checking: too small a cloud / missing output are refused with a message, not a fault
+    assert lib.gn_graspnet_forward(ctypes.byref(net._cweights), x.data_ptr(), B, 100, ws.data_ptr(), ctypes.byref(o),
+                                   L.STAGE_HOOK(), None, None) != 0
+    assert b"at least" in lib.gn_last_error()
+    o.head = None
+    assert lib.gn_graspnet_forward(ctypes.byref(net._cweights), x.data_ptr(), B, N, ws.data_ptr(), ctypes.byref(o),
+                                   L.STAGE_HOOK(), None, None) != 0
+
+
 def test_graph_captured_forward_matches_eager(net, clouds):
     """the forward + decode is hipGraph-capturable (no allocation / sync inside the C ABI) and replays identically"""
     from graspnet_amd import GraphedGraspNet

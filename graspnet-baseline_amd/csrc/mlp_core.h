@@ -113,9 +113,15 @@ struct StoreGlobal {
   }
 };
 
-__device__ __forceinline__ float xhalf_max(float v, int lane) {
-  const float o = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, v)));
-  return fmaxf(v, o);
+// max of a value with its partner in the other 32-lane half (the two halves of an accumulator column):
+// one v_permlane32_swap (gfx950: lanes 32-63 of the first operand swap with lanes 0-31 of the second) instead
+// of a trip through the LDS crossbar.  Inline asm: with ROCm 7.2 the builtin given two copies of one value
+// returned the same register twice (profiles/probe/permlane_test.hip).  s_nop 1 = the VALU-write -> permlane
+// read hazard.
+__device__ __forceinline__ float xhalf_max(float v, int /*lane*/) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
 }
 
 // ReLU + max over each group of NS consecutive positions -> out[group][ldo] (channels-last)

@@ -446,6 +446,21 @@ __global__ __launch_bounds__(MLP_THREADS, MINW) void crop_unique_mlp_kernel(cons
   }
 }
 
+// Phase probe (profiles/build_probe.sh, -DGN_PHASE_PROBE): per-wave cycle sums between marks, added into a global
+// table read by profiles/crop_phase_probe.py.  Compiled out of the product library.
+#ifdef GN_PHASE_PROBE
+__device__ unsigned long long gn_phase_probe[8 * 16];
+#define GN_PROBE_INIT() unsigned long long pt_[16] = {}; unsigned long long pl_ = __builtin_amdgcn_s_memtime()
+#define GN_PROBE(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pt_[i] += n_ - pl_; pl_ = n_; } while (0)
+#define GN_PROBE_COUNT(i, v) pt_[i] += (unsigned long long)(v)
+#define GN_PROBE_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&gn_phase_probe[(threadIdx.x >> 6) * 16 + i_], pt_[i_]); } while (0)
+#else
+#define GN_PROBE_INIT()
+#define GN_PROBE(i)
+#define GN_PROBE_COUNT(i, v)
+#define GN_PROBE_FLUSH()
+#endif
+
 // 8-wave flavour: two waves per SIMD, each owning half as many output channels (100 weight registers
 // instead of 164), so one wave's LDS / pooling epilogue runs under the other's MFMAs.
 template <int C1, int C2, int C3, int ND, int CAP, int TP>
@@ -514,6 +529,7 @@ __global__ __launch_bounds__(512) void crop_unique8_mlp_kernel(const float *__re
     if (tid < TP) { fetch(sf, row0, nu, tid, v, g); put(0, tid, v, g); }
   }
   __syncthreads();
+  GN_PROBE_INIT();
   while (true) {
     const int rows = min(TP, nu - row0);
     const int mtc = (rows + 31) >> 5;
@@ -528,25 +544,37 @@ __global__ __launch_bounds__(512) void crop_unique8_mlp_kernel(const float *__re
     const bool has_next = nsf < s_end;
     f32x4 nv, ng;
     if (has_next && tid < TP) fetch(nsf, nrow0, nnu, tid, nv, ng);   // in flight during the layers below
+    GN_PROBE(0);
 
     pool.sgate = bufG + buf * TP * 4;
     StoreLds<true> e1{bufY1, lds_stride(C1), C1, lane};
     run_layer<TP, CIN0, C1, StoreLds<true>, 8>(w1, bufX + buf * TP * XS0, wave, lane, e1, mtc);
+    GN_PROBE(1);
     __syncthreads();
+    GN_PROBE(2);
     StoreLds<true> e2{bufY2, lds_stride(C2), C2, lane};
     run_layer<TP, C1, C2, StoreLds<true>, 8>(w2, bufY1, wave, lane, e2, mtc);
+    GN_PROBE(3);
     __syncthreads();
+    GN_PROBE(4);
     run_layer<TP, C2, C3, PoolMasked<ND, L3::NTW>, 8>(w3, bufY2, wave, lane, pool, mtc);
+    GN_PROBE(5);
     if (seed_done) {
       pool.finish(out + (size_t)sf * ND * C3, C3, (wave % L3::WN) * L3::NTW);
       pool.reset();
     }
+    GN_PROBE(6);
     if (!has_next) break;
     if (tid < TP) put(buf ^ 1, tid, nv, ng);
+    GN_PROBE(7);
     __syncthreads();   // next input tile visible; Y1/Y2 free
+    GN_PROBE(8);
+    GN_PROBE_COUNT(9, 1);
+    GN_PROBE_COUNT(10, mtc);
     buf ^= 1;
     sf = nsf; row0 = nrow0; nu = nnu;
   }
+  GN_PROBE_FLUSH();
 }
 
 // tiles per block: amortise the per-block weight load over up to 8 tiles while keeping >= ~4 blocks
@@ -736,3 +764,14 @@ extern "C" int gn_sa_hoisted_mlp_pool(const float *xyz, const float *pfeat, cons
   GN_CHECK_LAUNCH("sa_hoisted_mlp_pool");
   return GN_OK;
 }
+
+#ifdef GN_PHASE_PROBE
+extern "C" int gn_phase_probe_read(unsigned long long *host, int reset) {
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(gn::gn_phase_probe), sizeof(unsigned long long) * 128) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[128] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gn::gn_phase_probe), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

@@ -10,7 +10,8 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)                      # graspnet-baseline_amd/
-LIB_PATH = os.path.join(_ROOT, "lib", "libgraspnet_hip.so")
+# GN_LIB_PATH: an alternative build of the same library (profiles/build_probe.sh: instrumented kernels)
+LIB_PATH = os.environ.get("GN_LIB_PATH") or os.path.join(_ROOT, "lib", "libgraspnet_hip.so")
 CSRC = os.path.join(_ROOT, "csrc")
 
 _lib = None

@@ -446,21 +446,6 @@ __global__ __launch_bounds__(MLP_THREADS, MINW) void crop_unique_mlp_kernel(cons
   }
 }
 
-// Phase probe (profiles/build_probe.sh, -DGN_PHASE_PROBE): per-wave cycle sums between marks, added into a global
-// table read by profiles/crop_phase_probe.py.  Compiled out of the product library.
-#ifdef GN_PHASE_PROBE
-__device__ unsigned long long gn_phase_probe[8 * 16];
-#define GN_PROBE_INIT() unsigned long long pt_[16] = {}; unsigned long long pl_ = __builtin_amdgcn_s_memtime()
-#define GN_PROBE(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pt_[i] += n_ - pl_; pl_ = n_; } while (0)
-#define GN_PROBE_COUNT(i, v) pt_[i] += (unsigned long long)(v)
-#define GN_PROBE_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&gn_phase_probe[(threadIdx.x >> 6) * 16 + i_], pt_[i_]); } while (0)
-#else
-#define GN_PROBE_INIT()
-#define GN_PROBE(i)
-#define GN_PROBE_COUNT(i, v)
-#define GN_PROBE_FLUSH()
-#endif
-
 // 8-wave flavour: two waves per SIMD, each owning half as many output channels (100 weight registers
 // instead of 164), so one wave's LDS / pooling epilogue runs under the other's MFMAs.
 template <int C1, int C2, int C3, int ND, int CAP, int TP>
@@ -765,13 +750,4 @@ extern "C" int gn_sa_hoisted_mlp_pool(const float *xyz, const float *pfeat, cons
   return GN_OK;
 }
 
-#ifdef GN_PHASE_PROBE
-extern "C" int gn_phase_probe_read(unsigned long long *host, int reset) {
-  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(gn::gn_phase_probe), sizeof(unsigned long long) * 128) != hipSuccess) return -1;
-  if (reset) {
-    unsigned long long z[128] = {};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(gn::gn_phase_probe), z, sizeof(z)) != hipSuccess) return -1;
-  }
-  return 0;
-}
-#endif
+GN_PROBE_READER(gn_phase_probe_read)

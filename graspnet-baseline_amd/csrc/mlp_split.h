@@ -1,0 +1,355 @@
+// mlp_split.h -- fp32 layers on the bf16 matrix cores by operand splitting ("bf16x3 operands, 6 products").
+//
+// Why.  v_mfma_f32_32x32x2_f32 runs on the SIMD's FP32 vector ALUs: 32 MAC/cycle/SIMD, and every other VALU
+// instruction of the kernel competes with it (profiles/probe/mfma_valu_overlap.hip).  The bf16 form
+// v_mfma_f32_32x32x16_bf16 runs on the matrix core at 512 MAC/cycle/SIMD with VALU work overlapped.  Each fp32
+// operand is therefore split exactly into three bf16 terms  x = x0 + x1 + x2  (x0 = bf16(x), x1 = bf16(x - x0),
+// x2 = bf16(x - x0 - x1): 3 x 8 significand bits), and
+//     x * w  ~=  x0w0 + (x0w1 + x1w0) + (x0w2 + x1w1 + x2w0)        (6 bf16 MFMAs per 16 k, fp32 accumulate)
+// The dropped terms x1w2 + x2w1 + x2w2 are <= 2^-23 |x||w|, the size of one fp32 rounding; every bf16 product is
+// exact in fp32 and a 16-k block is accumulated inside the MFMA, so the result is at least as close to the
+// float64 value as a k-ordered fp32 FMA chain (tests/test_split_gpu.py measures both against float64).
+// 6 x 32 cycles per 16 k instead of 8 x 64: 2.7x the fp32 MFMA rate, and the epilogues hide under the MFMAs.
+//
+// Layouts.  Activations live in LDS as three bf16 planes, position-major: plane p, row pos, k contiguous, row
+// stride C+8 elements ((C+8)/8 odd: conflict-free ds_read_b128).  A lane's operand fragment for k-block kb is the
+// 8 consecutive k at kb*16 + 8*(lane>>5) of row/column (lane&31) -- the same for the A and the B operand, so one
+// packed weight image serves both orientations:
+//     Wq[nt][kb][plane][lane][j] = W_plane[nt*32 + (lane&31)][kb*16 + 8*(lane>>5) + j]
+//   N orientation (A = activations, B = weights): D columns = channels, rows = positions -> pooling in-lane
+//   T orientation (A = weights, B = activations): D columns = positions, rows = channels -> a lane holds 4
+//     consecutive channels per register quad, i.e. one 8-byte store per plane into the next layer's tile
+#pragma once
+#include "mlp_core.h"
+
+namespace gn {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+
+__host__ __device__ constexpr int sp_stride(int c) { return c + 8; }   // bf16 elements per LDS row
+
+template <int CINP, int COUTP, int NWV = 4>
+struct LayerWS {
+  static_assert(CINP % 16 == 0 && COUTP % 32 == 0, "pad CIN to 16 and COUT to 32");
+  static constexpr int NT = COUTP / 32;
+  static constexpr int WN = wn_for(COUTP, NWV);
+  static constexpr int WM = NWV / WN;
+  static_assert(NT % WN == 0, "N tiles must divide over the waves");
+  static constexpr int NTW = NT / WN;
+  static constexpr int KB = CINP / 16;
+  bf16x8 b[NTW][KB][3];
+
+  __device__ __forceinline__ void load(const void *__restrict__ wp, int wave, int lane) {
+    const int wn = wave % WN;
+    const char *base = static_cast<const char *>(wp);
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          b[i][kb][p] = *reinterpret_cast<const bf16x8 *>(base + ((((size_t)((wn * NTW + i) * KB + kb)) * 3 + p) * 64 + lane) * 16);
+  }
+};
+
+// the six products of one 16-k block, small terms first; AW = true puts the weights on the A side (T orientation)
+template <bool AW>
+__device__ __forceinline__ f32x16 mfma6(const bf16x8 (&x)[3], const bf16x8 (&w)[3], f32x16 acc) {
+  constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
+  constexpr int WI[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+  for (int t = 0; t < 6; ++t)
+    acc = AW ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[WI[t]], x[XI[t]], acc, 0, 0, 0)
+             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[XI[t]], w[WI[t]], acc, 0, 0, 0);
+  return acc;
+}
+
+// exact three-way split of four fp32 values (ReLU first if asked)
+template <bool RELU>
+__device__ __forceinline__ void split4(float v0, float v1, float v2, float v3, bf16x4 &hi, bf16x4 &mid, bf16x4 &lo) {
+  float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float x = RELU ? fmaxf(v[j], 0.f) : v[j];
+    hi[j] = (__bf16)x;
+    const float r = x - (float)hi[j];
+    mid[j] = (__bf16)r;
+    const float r2 = r - (float)mid[j];
+    lo[j] = (__bf16)r2;
+  }
+}
+
+// T-orientation epilogue: ReLU, split, store the tile into the next layer's three planes
+struct StoreSplit {
+  __bf16 *ys;     // plane 0
+  int stride;     // elements per row
+  int plane;      // elements per plane
+  int lane;
+  __device__ __forceinline__ void operator()(int mt, int nt, const f32x16 &acc) {
+    __bf16 *row = ys + (mt * 32 + (lane & 31)) * stride + nt * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 hi, mid, lo;
+      split4<true>(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], hi, mid, lo);
+      *reinterpret_cast<bf16x4 *>(row + 8 * g) = hi;
+      *reinterpret_cast<bf16x4 *>(row + 8 * g + plane) = mid;
+      *reinterpret_cast<bf16x4 *>(row + 8 * g + 2 * plane) = lo;
+    }
+  }
+};
+
+// bias of the 16 accumulator rows of n-tile nt in T orientation (rows = channels)
+__device__ __forceinline__ void load_bias_t(const float *__restrict__ bp, int nt, int lane, float (&bt)[16]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bt[r] = bp[nt * 32 + acc_row(r, lane)];
+}
+
+// ---- T orientation: Y[pos][cout] planes <- relu(W * X + b), X read from three bf16 planes ------------------
+template <int TP, int CINP, int COUTP, int NWV = 4>
+__device__ __forceinline__ void run_layer_split_t(const LayerWS<CINP, COUTP, NWV> &w, const float (&bias_t)[16],
+                                                  const __bf16 *__restrict__ xs, int xplane, int wave, int lane,
+                                                  StoreSplit &epi, int mt_count = TP / 32) {
+  using LW = LayerWS<CINP, COUTP, NWV>;
+  static_assert(LW::NTW == 1, "T-orientation layers keep one n-tile per wave (16 bias registers each)");
+  constexpr int XS = sp_stride(CINP), KB = LW::KB;
+  const int wm = wave / LW::WN, wn = wave % LW::WN;
+  for (int mt = wm; mt < mt_count; mt += LW::WM) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bias_t[r];
+    const __bf16 *xr = xs + (mt * 32 + (lane & 31)) * XS + 8 * (lane >> 5);
+    bf16x8 a[KB][3];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[kb][p] = *reinterpret_cast<const bf16x8 *>(xr + p * xplane + kb * 16);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) acc = mfma6<true>(a[kb], w.b[0][kb], acc);
+    if constexpr (KB > 2) {   // [6 reads] ([6 MFMAs][3 reads])* : operands two k-blocks ahead of their MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+      for (int kb = 0; kb < KB - 2; ++kb) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+    }
+    epi(mt, wn, acc);
+  }
+}
+
+// ---- N orientation: acc[pos][cout] = X * W^T + b handed to a pooling epilogue (PoolMasked / PoolGlobal) -------
+template <int TP, int CINP, int COUTP, class Epi, int NWV = 4>
+__device__ __forceinline__ void run_layer_split_n(const LayerWS<CINP, COUTP, NWV> &w, const float (&bias)[LayerWS<CINP, COUTP, NWV>::NTW],
+                                                  const __bf16 *__restrict__ xs, int xplane, int wave, int lane, Epi &epi,
+                                                  int mt_count = TP / 32) {
+  using LW = LayerWS<CINP, COUTP, NWV>;
+  constexpr int XS = sp_stride(CINP), KB = LW::KB, NTW = LW::NTW;
+  const int wm = wave / LW::WN, wn = wave % LW::WN;
+  for (int mt = wm; mt < mt_count; mt += LW::WM) {
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = bias[i];
+    const __bf16 *xr = xs + (mt * 32 + (lane & 31)) * XS + 8 * (lane >> 5);
+    bf16x8 a[KB][3];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[kb][p] = *reinterpret_cast<const bf16x8 *>(xr + p * xplane + kb * 16);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) acc[i] = mfma6<false>(a[kb], w.b[i][kb], acc[i]);
+    if constexpr (KB > 2) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+      for (int kb = 0; kb < KB - 2; ++kb) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * NTW, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 12 * NTW, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) epi(mt, wn * NTW + i, i, acc[i]);
+  }
+}
+
+// ---- software-pipelined forms.  The bf16 MFMA runs on the matrix core and VALU / LDS instructions of the same wave
+// issue in its shadow (profiles/probe/mfma_bf16_overlap.hip: <= 4 fillers per MFMA are nearly free), so the epilogue of
+// output tile u is spread over the MFMAs of tile u+1.  The source is written step by step (one 16-k block = 6 MFMAs
+// per step) with a sched_barrier closing each step, and sched_group_barriers asking for 1 MFMA : NV VALU inside it.
+template <int NV>
+__device__ __forceinline__ void interleave_step(int nreads, int nwrites) {
+  (void)nreads; (void)nwrites;
+#pragma unroll
+  for (int t = 0; t < 6; ++t) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+  }
+}
+
+// T orientation, one n-tile per wave: split + store of M tile t under the MFMAs of M tile t+1
+template <int TP, int CINP, int COUTP, int NWV = 4>
+__device__ __forceinline__ void run_layer_split_t_pipe(const LayerWS<CINP, COUTP, NWV> &w, const float (&bias_t)[16],
+                                                       const __bf16 *__restrict__ xs, int xplane, int wave, int lane,
+                                                       StoreSplit &epi, int mt_count = TP / 32) {
+  using LW = LayerWS<CINP, COUTP, NWV>;
+  static_assert(LW::NTW == 1 && LW::WM == 1 && LW::KB == 4, "one n-tile per wave, every wave walks all M tiles, K = 64");
+  constexpr int XS = sp_stride(CINP), KB = LW::KB, MAXU = TP / 32;
+  const int wn = wave % LW::WN;
+  if (mt_count <= 0) return;
+  f32x16 acc[2];
+  auto mma = [&](f32x16 &dst, int mt, auto &&fill) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[r] = bias_t[r];
+    const __bf16 *xr = xs + (mt * 32 + (lane & 31)) * XS + 8 * (lane >> 5);
+    bf16x8 a[KB][3];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[kb][p] = *reinterpret_cast<const bf16x8 *>(xr + p * xplane + kb * 16);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      if (kb + 2 < KB) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[kb + 2][p] = *reinterpret_cast<const bf16x8 *>(xr + p * xplane + (kb + 2) * 16);
+      }
+      dst = mfma6<true>(a[kb], w.b[0][kb], dst);
+      fill(kb);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      interleave_step<6>(3, 3);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // one quarter (4 channels x this lane's position) of a finished tile
+  auto store_quarter = [&](const f32x16 &src, int mt, int g) {
+    __bf16 *row = epi.ys + (mt * 32 + (lane & 31)) * epi.stride + wn * 32 + 4 * (lane >> 5) + 8 * g;
+    bf16x4 hi, mid, lo;
+    split4<true>(src[4 * g], src[4 * g + 1], src[4 * g + 2], src[4 * g + 3], hi, mid, lo);
+    *reinterpret_cast<bf16x4 *>(row) = hi;
+    *reinterpret_cast<bf16x4 *>(row + epi.plane) = mid;
+    *reinterpret_cast<bf16x4 *>(row + 2 * epi.plane) = lo;
+  };
+  mma(acc[0], 0, [](int) {});
+#pragma unroll
+  for (int u = 1; u < MAXU; ++u) {
+    if (u < mt_count) {
+      mma(acc[u & 1], u, [&](int kb) { store_quarter(acc[(u - 1) & 1], u - 1, kb); });
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) store_quarter(acc[(u - 1) & 1], u - 1, g);
+      return;
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) store_quarter(acc[(MAXU - 1) & 1], MAXU - 1, g);
+}
+
+// N orientation with the masked-pool epilogue: unit = (M tile, n-tile of this wave); pooling of unit u (8 slices of two
+// accumulator rows, gates read one step ahead) under the MFMAs of unit u+1.  Same arithmetic as run_layer_split_n.
+// (A stricter variant -- one pool depth pinned behind each MFMA, operands prefetched across units -- reaches the same
+// 47 cycles/MFMA in profiles/probe/split_layer_bench.hip and spills in the full kernel: the VALU budget per MFMA gap is
+// ~4 instructions and the pool needs ~4 plus accumulator moves.)
+template <int TP, int CINP, int COUTP, int ND, int NWV = 4>
+__device__ __forceinline__ void run_layer_split_n_pool_pipe(const LayerWS<CINP, COUTP, NWV> &w,
+                                                            const float (&bias)[LayerWS<CINP, COUTP, NWV>::NTW],
+                                                            const __bf16 *__restrict__ xs, int xplane, int wave, int lane,
+                                                            PoolMasked<ND, LayerWS<CINP, COUTP, NWV>::NTW> &pool, int mt_count) {
+  using LW = LayerWS<CINP, COUTP, NWV>;
+  static_assert(LW::WM == 1 && LW::KB == 8, "every wave walks all M tiles; 8 pool slices ride on 8 k-blocks");
+  constexpr int XS = sp_stride(CINP), KB = LW::KB, NTW = LW::NTW, MAXU = (TP / 32) * NTW;
+  const int nunits = mt_count * NTW;
+  if (nunits == 0) return;
+  f32x16 acc[2];
+  const __bf16 *xbase = xs + (lane & 31) * XS + 8 * (lane >> 5);
+  const float *gbase = pool.sgate + (4 * (lane >> 5)) * 4;
+  f32x4 g[8][2];
+  auto gate_read = [&](int mt, int j) {
+    const int r = 2 * j;
+    const int rb = (r & 3) + 8 * (r >> 2);
+    g[j][0] = *reinterpret_cast<const f32x4 *>(gbase + (mt * 32 + rb) * 4);
+    g[j][1] = *reinterpret_cast<const f32x4 *>(gbase + (mt * 32 + rb + 1) * 4);
+  };
+  auto pool_slice = [&](const f32x16 &src, int i, int j) {
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+      pool.hold[d][i] = fmaxf(pool.hold[d][i], fmaxf(src[2 * j] + g[j][0][d], src[2 * j + 1] + g[j][1][d]));
+  };
+  auto mma = [&](f32x16 &dst, int mt, int i, auto &&pre, auto &&fill) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[r] = bias[i];
+    const __bf16 *xr = xbase + mt * 32 * XS;
+    bf16x8 a[KB][3];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[kb][p] = *reinterpret_cast<const bf16x8 *>(xr + p * xplane + kb * 16);
+    pre();
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      if (kb + 2 < KB) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[kb + 2][p] = *reinterpret_cast<const bf16x8 *>(xr + p * xplane + (kb + 2) * 16);
+      }
+      fill(kb, 0);
+      dst = mfma6<false>(a[kb], w.b[i][kb], dst);
+      fill(kb, 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+      interleave_step<3>(5, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  mma(acc[0], 0, 0, []() {}, [](int, int) {});
+#pragma unroll
+  for (int u = 1; u < MAXU; ++u) {
+    const int pmt = (u - 1) / NTW, pi = (u - 1) % NTW;
+    if (u < nunits) {
+      mma(acc[u & 1], u / NTW, u % NTW, [&]() { gate_read(pmt, 0); },
+          [&](int kb, int phase) {
+            if (phase == 0) {
+              if (kb + 1 < 8) gate_read(pmt, kb + 1);
+            } else {
+              pool_slice(acc[(u - 1) & 1], pi, kb);
+            }
+          });
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gate_read(pmt, j);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pool_slice(acc[(u - 1) & 1], pi, j);
+      return;
+    }
+  }
+  {
+    constexpr int pmt = (MAXU - 1) / NTW, pi = (MAXU - 1) % NTW;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gate_read(pmt, j);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pool_slice(acc[(MAXU - 1) & 1], pi, j);
+  }
+}
+
+// ---- first layer (K = 3 coordinates, padded to 8) stays on the fp32 MFMA, T orientation, split epilogue -------
+template <int TP, int COUTP, int NWV = 4>
+__device__ __forceinline__ void run_layer_f32_t(const LayerW<8, COUTP, NWV> &w, const float (&bias_t)[16],
+                                                const float *__restrict__ xs, int wave, int lane, StoreSplit &epi,
+                                                int mt_count = TP / 32) {
+  using LW = LayerW<8, COUTP, NWV>;
+  static_assert(LW::NTW == 1, "one n-tile per wave");
+  constexpr int XS = lds_stride(8);
+  const int wm = wave / LW::WN, wn = wave % LW::WN;
+  for (int mt = wm; mt < mt_count; mt += LW::WM) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bias_t[r];
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(xs + (mt * 32 + (lane & 31)) * XS + 4 * (lane >> 5));
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.b[0][0][s], a[s], acc, 0, 0, 0);
+    epi(mt, wn, acc);
+  }
+}
+
+}  // namespace gn

@@ -1,0 +1,195 @@
+// mlp_split.hip -- grouped MLP kernels with layers 2-3 on the bf16 matrix cores (split operands, mlp_split.h).
+//
+// gn_crop_unique_mlp_pool_split: CloudCrop's SharedMLP[3,64,128,256] + masked max-pool over the de-duplicated
+// rows of each seed (models/modules.py:131-140, pointnet2_utils.py:521-530), same interface and row semantics as
+// gn_crop_unique_mlp_pool; layer 1 (K = 3) stays on the fp32 MFMA.
+#include <stdlib.h>
+
+#include "mlp_split.h"
+
+namespace gn {
+
+struct SplitWeights {
+  const float *w1, *b1;        // layer 1: fp32 fragments (mlp_core.h)
+  const void *w2, *w3;         // layers 2-3: split-bf16 fragments (mlp_split.h)
+  const float *b2, *b3;
+};
+
+template <class K>
+static int set_lds_attr(K kernel, size_t bytes, const char *name) {
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)bytes) != hipSuccess) {
+    set_error("%s: cannot reserve %zu bytes of LDS", name, bytes);
+    return GN_ERR_LAUNCH;
+  }
+  return GN_OK;
+}
+
+// One workgroup (4 waves) walks `spb` consecutive seeds; a seed's rows are taken in chunks of <= TP.
+// LDS: Y2 3 planes [TP][C2+8] bf16, Y1 3 planes [TP][C1+8] bf16, X 2 x [TP][12] f32, gates 2 x [TP][4] f32.
+template <int C1, int C2, int C3, int ND, int CAP, int TP, int PIPE>
+__global__ __launch_bounds__(MLP_THREADS) void crop_unique_split_kernel(const float *__restrict__ xyz, int n,
+                                                                        const float *__restrict__ seed,
+                                                                        const float *__restrict__ rot,
+                                                                        const int32_t *__restrict__ uidx,
+                                                                        const int32_t *__restrict__ ucount, int m,
+                                                                        int nseeds, int spb, SplitWeights W,
+                                                                        float *__restrict__ out) {
+  constexpr int CIN0 = 8, XS0 = lds_stride(CIN0);
+  constexpr int P2 = TP * sp_stride(C2), P1 = TP * sp_stride(C1);
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __bf16 *bufY2 = reinterpret_cast<__bf16 *>(smem_raw);            // 3 x [TP][C2+8]
+  __bf16 *bufY1 = bufY2 + 3 * P2;                                  // 3 x [TP][C1+8]
+  float *bufX = reinterpret_cast<float *>(bufY1 + 3 * P1);         // 2 x [TP][12]
+  float *bufG = bufX + 2 * TP * XS0;                               // 2 x [TP][4] pooling gates
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  LayerW<CIN0, C1> w1;
+  LayerWS<C1, C2> w2;
+  LayerWS<C2, C3> w3;
+  using L1 = LayerW<CIN0, C1>;
+  using L2 = LayerWS<C1, C2>;
+  using L3 = LayerWS<C2, C3>;
+  w1.load(W.w1, W.b1, wave, lane);
+  w2.load(W.w2, wave, lane);
+  w3.load(W.w3, wave, lane);
+  float b1t[16], b2t[16], b3[L3::NTW];
+  load_bias_t(W.b1, wave % L1::WN, lane, b1t);
+  load_bias_t(W.b2, wave % L2::WN, lane, b2t);
+#pragma unroll
+  for (int i = 0; i < L3::NTW; ++i) b3[i] = W.b3[((wave % L3::WN) * L3::NTW + i) * 32 + (lane & 31)];
+  PoolMasked<ND, L3::NTW> pool{bufG, lane, {}};
+  pool.reset();
+
+  const int s_end = min(nseeds, (int)(blockIdx.x + 1) * spb);
+  int sf = blockIdx.x * spb;
+  if (sf >= s_end) return;
+  int nu = ucount[sf], row0 = 0;
+
+  auto fetch = [&](int csf, int crow0, int cnu, int p, f32x4 &v, f32x4 &g) {
+    v = f32x4{0.f, 0.f, 0.f, 0.f};
+    g = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (crow0 + p < cnu) {
+      const int e = uidx[(size_t)csf * CAP + crow0 + p];
+      const int src = e & 0x0fffffff;
+      const unsigned mk = (unsigned)e >> 28;
+      const float *c = seed + (size_t)csf * 3;
+      const float *r = rot + (size_t)csf * 9;
+      const float *px = xyz + (size_t)(csf / m) * n * 3;
+      const float x = px[src * 3 + 0] - c[0];
+      const float y = px[src * 3 + 1] - c[1];
+      const float z = px[src * 3 + 2] - c[2];
+      v[0] = x * r[0] + y * r[3] + z * r[6];   // (p-c)^T R, pointnet2_utils.py:528-530
+      v[1] = x * r[1] + y * r[4] + z * r[7];
+      v[2] = x * r[2] + y * r[5] + z * r[8];
+#pragma unroll
+      for (int d = 0; d < ND; ++d) g[d] = ((mk >> d) & 1u) ? 0.f : -INFINITY;
+    }
+  };
+  auto put = [&](int buf, int p, const f32x4 &v, const f32x4 &g) {
+    float *x = bufX + buf * TP * XS0 + p * XS0;
+    *reinterpret_cast<f32x4 *>(x) = v;
+    *reinterpret_cast<f32x4 *>(x + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4 *>(bufG + buf * TP * 4 + p * 4) = g;
+  };
+
+  int buf = 0;
+  {
+    f32x4 v, g;
+    if (tid < TP) { fetch(sf, row0, nu, tid, v, g); put(0, tid, v, g); }
+  }
+  __syncthreads();
+  GN_PROBE_INIT();
+  while (true) {
+    const int rows = min(TP, nu - row0);
+    const int mtc = (rows + 31) >> 5;
+    const bool seed_done = row0 + TP >= nu;
+    int nsf = sf, nrow0 = row0 + TP, nnu = nu;
+    if (seed_done) {
+      nsf = sf + 1;
+      nrow0 = 0;
+      nnu = nsf < s_end ? ucount[nsf] : 0;
+    }
+    const bool has_next = nsf < s_end;
+    f32x4 nv, ng;
+    if (has_next && tid < TP) fetch(nsf, nrow0, nnu, tid, nv, ng);   // in flight during the layers below
+    GN_PROBE(0);
+
+    pool.sgate = bufG + buf * TP * 4;
+    StoreSplit e1{bufY1, sp_stride(C1), P1, lane};
+    run_layer_f32_t<TP, C1>(w1, b1t, bufX + buf * TP * XS0, wave, lane, e1, mtc);
+    GN_PROBE(1);
+    __syncthreads();
+    GN_PROBE(2);
+    StoreSplit e2{bufY2, sp_stride(C2), P2, lane};
+    if constexpr (PIPE & 1)
+      run_layer_split_t_pipe<TP, C1, C2>(w2, b2t, bufY1, P1, wave, lane, e2, mtc);
+    else
+      run_layer_split_t<TP, C1, C2>(w2, b2t, bufY1, P1, wave, lane, e2, mtc);
+    GN_PROBE(3);
+    __syncthreads();
+    GN_PROBE(4);
+    if constexpr (PIPE & 2)
+      run_layer_split_n_pool_pipe<TP, C2, C3, ND>(w3, b3, bufY2, P2, wave, lane, pool, mtc);
+    else
+      run_layer_split_n<TP, C2, C3>(w3, b3, bufY2, P2, wave, lane, pool, mtc);
+    GN_PROBE(5);
+    if (seed_done) {
+      pool.finish(out + (size_t)sf * ND * C3, C3, (wave % L3::WN) * L3::NTW);
+      pool.reset();
+    }
+    GN_PROBE(6);
+    if (!has_next) break;
+    if (tid < TP) put(buf ^ 1, tid, nv, ng);
+    GN_PROBE(7);
+    __syncthreads();   // next input tile visible; Y1/Y2 free
+    GN_PROBE(8);
+    GN_PROBE_COUNT(9, 1);
+    GN_PROBE_COUNT(10, mtc);
+    buf ^= 1;
+    sf = nsf; row0 = nrow0; nu = nnu;
+  }
+  GN_PROBE_FLUSH();
+}
+
+}  // namespace gn
+
+using namespace gn;
+
+extern "C" int gn_crop_unique_mlp_pool_split(const float *xyz, const float *seed_xyz, const float *rot, const int32_t *uidx,
+                                             const int32_t *ucount, int b, int n, int m, int ndepth, int ns, const int *mlp,
+                                             const void *const *wpacked, const float *const *bias, float *out,
+                                             gn_stream_t stream) {
+  GN_REQUIRE(b >= 0 && n > 0 && m > 0, "crop_unique_mlp_pool_split: bad sizes");
+  if (b == 0) return GN_OK;
+  GN_REQUIRE(xyz && seed_xyz && rot && uidx && ucount && mlp && wpacked && bias && out,
+             "crop_unique_mlp_pool_split: null pointer");
+  GN_REQUIRE((long)n * 3 < 0x7fffffffL, "crop_unique_mlp_pool_split: n too large");
+  if (!(ndepth == 4 && ns == 64 && mlp[0] == 64 && mlp[1] == 128 && mlp[2] == 256)) {
+    set_error("crop_unique_mlp_pool_split: unsupported configuration depth=%d nsample=%d mlp=[%d,%d,%d]", ndepth, ns,
+              mlp[0], mlp[1], mlp[2]);
+    return GN_ERR_INVALID_ARG;
+  }
+  const SplitWeights W{static_cast<const float *>(wpacked[0]), bias[0], wpacked[1], wpacked[2], bias[1], bias[2]};
+  const int nseeds = b * m;
+  int spb = nseeds / 2048;
+  spb = spb < 1 ? 1 : (spb > 8 ? 8 : spb);
+  constexpr int TP = 96;
+  constexpr size_t lds = 2 * (3 * TP * sp_stride(128) + 3 * TP * sp_stride(64)) + sizeof(float) * (2 * TP * lds_stride(8) + 2 * TP * 4);
+  static const int pipe = []() { const char *e = getenv("GN_SPLIT_PIPE"); return e ? atoi(e) : 3; }();
+  int rc = GN_OK;
+  auto launch = [&](auto k) {
+    if ((rc = set_lds_attr(k, lds, "crop_unique_mlp_pool_split"))) return;
+    hipLaunchKernelGGL(k, dim3((nseeds + spb - 1) / spb), dim3(MLP_THREADS), lds, as_stream(stream), xyz, n, seed_xyz, rot,
+                       uidx, ucount, m, nseeds, spb, W, out);
+  };
+  if (pipe == 0) launch(crop_unique_split_kernel<64, 128, 256, 4, 256, TP, 0>);
+  else if (pipe == 1) launch(crop_unique_split_kernel<64, 128, 256, 4, 256, TP, 1>);
+  else if (pipe == 2) launch(crop_unique_split_kernel<64, 128, 256, 4, 256, TP, 2>);
+  else launch(crop_unique_split_kernel<64, 128, 256, 4, 256, TP, 3>);
+  if (rc) return rc;
+  GN_CHECK_LAUNCH("crop_unique_mlp_pool_split");
+  return GN_OK;
+}
+
+GN_PROBE_READER(gn_phase_probe_read_split)

@@ -69,6 +69,9 @@ SIGNATURES = {
     "gn_crop_unique_mlp_pool": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                          _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_void_p),
                                          ctypes.POINTER(_c_void_p), _c_void_p, _c_void_p]),
+    "gn_crop_unique_mlp_pool_split": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
+                                               _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_void_p),
+                                               ctypes.POINTER(_c_void_p), _c_void_p, _c_void_p]),
     "gn_sa_group_mlp_pool": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                       _c_float, ctypes.POINTER(_c_int), ctypes.POINTER(_c_void_p),
                                       ctypes.POINTER(_c_void_p), _c_void_p, _c_void_p]),

@@ -64,6 +64,8 @@ class GraspNet:
         # forward); GN_FORWARD=stages issues the same stage calls one by one from here (always used for the
         # non-default A/B paths above)
         self.native_forward = os.environ.get("GN_FORWARD", "native") != "stages"
+        # layers on the bf16 matrix cores by exact operand splitting (csrc/mlp_split.h) instead of the fp32 MFMA
+        self.math_split = os.environ.get("GN_MATH", "f32") == "split"
 
     def _run(self, name, status_fn):
         """Issue one C-ABI call; when self.timing is a dict, bracket it with events on the launch stream."""
@@ -228,7 +230,8 @@ class GraspNet:
             xyz = pc[..., 0:3].contiguous()                      # backbone.py:69-75 _break_up_pc
             end_points["input_xyz"] = xyz
             end_points["input_features"] = None
-            if self.native_forward and self.crop_unique and self.sa_hoist and self.query_grid and N >= SA_CFG[0][0]:
+            if (self.native_forward and self.crop_unique and self.sa_hoist and self.query_grid and not self.math_split
+                    and N >= SA_CFG[0][0]):
                 return self._forward_native(end_points, xyz)
 
             # ---- 4 set-abstraction levels (backbone.py:105-121)
@@ -340,9 +343,15 @@ class GraspNet:
                     self._run("cylinder_query_unique", lambda: lib.gn_cylinder_query_unique(
                         seed_xyz.data_ptr(), xyz.data_ptr(), top_rot.data_ptr(), B, N, M, self.cylinder_radius, self.hmin,
                         self.hmax, D, NS, uidx.data_ptr(), ucount.data_ptr(), st))
-                self._run("crop_unique_mlp_pool", lambda: lib.gn_crop_unique_mlp_pool(
-                    xyz.data_ptr(), seed_xyz.data_ptr(), top_rot.data_ptr(), uidx.data_ptr(), ucount.data_ptr(), B, N, M,
-                    D, NS, _ci(64, 128, 256), pk.wptr, pk.bptr, vp.data_ptr(), st))
+                if self.math_split:
+                    pks = self._packed["crop_split"]
+                    self._run("crop_unique_mlp_pool", lambda: lib.gn_crop_unique_mlp_pool_split(
+                        xyz.data_ptr(), seed_xyz.data_ptr(), top_rot.data_ptr(), uidx.data_ptr(), ucount.data_ptr(), B, N,
+                        M, D, NS, _ci(64, 128, 256), pks.wptr, pks.bptr, vp.data_ptr(), st))
+                else:
+                    self._run("crop_unique_mlp_pool", lambda: lib.gn_crop_unique_mlp_pool(
+                        xyz.data_ptr(), seed_xyz.data_ptr(), top_rot.data_ptr(), uidx.data_ptr(), ucount.data_ptr(), B, N,
+                        M, D, NS, _ci(64, 128, 256), pk.wptr, pk.bptr, vp.data_ptr(), st))
                 crop_priv = {"uidx": uidx, "ucount": ucount}
             else:
                 cyl_idx = torch.empty((B, M, D, NS), dtype=i32, device=dev)

@@ -45,6 +45,31 @@ def pack_fragments(w, b, cinp=None, coutp=None):
     return frag.contiguous(), bp
 
 
+def split3(w):
+    """fp32 -> three bf16 terms with w == hi + mid + lo to ~2^-24 (each residual is exact in fp32)."""
+    hi = w.to(torch.bfloat16)
+    r = w - hi.float()
+    mid = r.to(torch.bfloat16)
+    lo = (r - mid.float()).to(torch.bfloat16)
+    return hi, mid, lo
+
+
+def pack_split(w, b, cinp=None, coutp=None):
+    """(Cout,Cin) f32 -> Wq[nt][kb][plane][lane][j] bf16 = W_plane[nt*32+(lane&31)][kb*16+8*(lane>>5)+j] (csrc/mlp_split.h),
+    padded fp32 bias."""
+    cout, cin = w.shape
+    cinp = pad_to(cin, 16) if cinp is None else cinp
+    coutp = coutp_for(cout) if coutp is None else coutp
+    wp = torch.zeros(coutp, cinp, dtype=torch.float32)
+    wp[:cout, :cin] = w
+    bp = torch.zeros(coutp, dtype=torch.float32)
+    bp[:cout] = b
+    nt, kb = coutp // 32, cinp // 16
+    planes = torch.stack(split3(wp), 0)                                   # (3, coutp, cinp)
+    frag = planes.reshape(3, nt, 32, kb, 2, 8).permute(1, 3, 0, 4, 2, 5).contiguous().reshape(nt, kb, 3, 64, 8)
+    return frag.contiguous(), bp
+
+
 class PackedMlp:
     """Device-resident packed layers + the ctypes pointer arrays the C ABI takes."""
 
@@ -92,8 +117,11 @@ def prepare(sd, device, num_view=300, num_angle=12):
     nvp = coutp_for(nv)
     out["approach"] = PackedMlp([pack_fragments(*l1), pack_fragments(*l2, coutp=nvp),
                                  pack_fragments(*l3, cinp=pad_to(nv, 32), coutp=nvp)], device)   # K padded to 320: chunks of 80
-    out["crop"] = PackedMlp([pack_fragments(w, b, cinp=8 if i == 0 else None)
-                             for i, (w, b) in enumerate(_shared_mlp_layers(sd, "grasp_generator.crop.mlps", 3))], device)
+    crop_layers = _shared_mlp_layers(sd, "grasp_generator.crop.mlps", 3)
+    out["crop"] = PackedMlp([pack_fragments(w, b, cinp=8 if i == 0 else None) for i, (w, b) in enumerate(crop_layers)], device)
+    # layers 2-3 as split-bf16 fragments for the matrix-core path (layer 1, K = 3, stays fp32)
+    out["crop_split"] = PackedMlp([pack_fragments(*crop_layers[0], cinp=8), pack_split(*crop_layers[1]),
+                                   pack_split(*crop_layers[2])], device)
     # OperationNet + ToleranceNet as one chain: conv1 stacked, conv2 / conv3 block-diagonal
     op, tl = "grasp_generator.operation", "grasp_generator.tolerance"
     o1 = fold_bn(sd[op + ".conv1.weight"], sd[op + ".conv1.bias"], sd, op + ".bn1")

@@ -205,6 +205,16 @@ int gn_crop_unique_mlp_pool(const float *xyz, const float *seed_xyz, const float
                             const float *const *wpacked, const float *const *bias, float *out,
                             gn_stream_t stream);
 
+/* gn_crop_unique_mlp_pool with layers 2-3 on the bf16 matrix cores by exact operand splitting (each fp32 operand =
+ * three bf16 terms, six products per 16 k, fp32 accumulate: csrc/mlp_split.h; error vs float64 no larger than the
+ * fp32 FMA chain's).  wpacked[0]: layer 1 in the fp32 fragment layout above; wpacked[1..2]: split fragments
+ *   Wq[nt][kb][plane][lane][j] (bf16) = W_plane[nt*32 + (lane&31)][kb*16 + 8*(lane>>5) + j],  plane = hi, mid, lo
+ * (graspnet_amd/weights.py: pack_split).  Same rows, masks and output as gn_crop_unique_mlp_pool. */
+int gn_crop_unique_mlp_pool_split(const float *xyz, const float *seed_xyz, const float *rot, const int32_t *uidx,
+                                  const int32_t *ucount, int b, int n, int m, int ndepth, int ns, const int *mlp,
+                                  const void *const *wpacked, const float *const *bias, float *out,
+                                  gn_stream_t stream);
+
 /* PointnetFPModule tail (pointnet2_modules.py:395-416): inverse-distance weights from three_nn's
  * dist2/idx, three_interpolate, concat skip features, SharedMLP(2 layers).
  * known_feat (B,m,ck), skip_feat (B,n,cs) channels-last -> out (B,n,mlp[1]). */

@@ -17,7 +17,7 @@ buf = (ctypes.c_ulonglong * 128)()
 for it in range(3):
     net({"point_clouds": x})
     torch.cuda.synchronize()
-    lib.gn_phase_probe_read(buf, 1)
+    (lib.gn_phase_probe_read_split if net.math_split else lib.gn_phase_probe_read)(buf, 1)
 names = ["fetch-issue", "L1", "bar1", "L2", "bar2", "L3+pool", "finish", "put", "bar3", "chunks", "mtiles"]
 tot_all = 0
 for w in range(8):

@@ -1,0 +1,79 @@
+"""GPU: the split-bf16 matrix-core layers (csrc/mlp_split.h) against float64 and against the fp32 MFMA path.
+
+Each fp32 operand is split exactly into three bf16 terms and six of the nine products are accumulated in fp32; the
+claim tested here is that this is AS ACCURATE as fp32 arithmetic: error against a float64 evaluation of the same
+layers no larger than the error of the fp32 CPU oracle (and of the fp32 MFMA kernel)."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def clouds():
+    from graspnet_amd import synthetic as S
+    return S.make_batch(1000, 2, 20000, "uniform")
+
+
+@pytest.fixture(scope="module")
+def ref(model_oracle, state_dict, clouds):
+    return model_oracle.forward({"point_clouds": clouds.clone()}, state_dict, keep_internal=True)
+
+
+@pytest.fixture(scope="module")
+def truth(model_oracle, state_dict, clouds, ref):
+    return model_oracle.forward({"point_clouds": clouds.clone()}, state_dict, f64=True, keep_internal=True,
+                                force_top_view_inds=ref["grasp_top_view_inds"])
+
+
+@pytest.fixture(scope="module")
+def net(state_dict):
+    from graspnet_amd import GraspNet
+    return GraspNet(is_training=False).load_state_dict(state_dict)
+
+
+def _errs(x, t):
+    e = (x.double().cpu() - t.double()).abs()
+    return float(e.max()), float(e.pow(2).mean().sqrt())
+
+
+def test_split_weights_are_exact(net):
+    from graspnet_amd import weights as W
+    w = torch.randn(256, 128) * torch.logspace(-4, 2, 128)[None, :]
+    hi, mid, lo = W.split3(w)
+    back = hi.double() + mid.double() + lo.double()
+    assert float(((back - w.double()).abs() / w.double().abs().clamp_min(1e-30)).max()) <= 2.0 ** -22
+
+
+def test_crop_split_matches_float64_as_well_as_fp32(ref, truth, net):
+    from graspnet_amd import _lib as L
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    B, N, M = 2, 20000, 1024
+    xyz = ref["input_xyz"].cuda()
+    seed = ref["fp2_xyz"].cuda()
+    rot = ref["grasp_top_view_rot"].reshape(B, M, 9).contiguous().cuda()
+    uidx = torch.empty((B, M, 256), dtype=torch.int32, device="cuda")
+    ucount = torch.empty((B, M), dtype=torch.int32, device="cuda")
+    hmax = (ctypes.c_float * 4)(0.01, 0.02, 0.03, 0.04)
+    L.check(lib.gn_cylinder_query_unique(seed.data_ptr(), xyz.data_ptr(), rot.data_ptr(), B, N, M, 0.05, -0.02, hmax, 4, 64,
+                                         uidx.data_ptr(), ucount.data_ptr(), st), "cyl")
+    mlp = (ctypes.c_int * 3)(64, 128, 256)
+    v32 = torch.empty((B, M * 4, 256), device="cuda")
+    vsp = torch.empty((B, M * 4, 256), device="cuda")
+    pk, pks = net._packed["crop"], net._packed["crop_split"]
+    L.check(lib.gn_crop_unique_mlp_pool(xyz.data_ptr(), seed.data_ptr(), rot.data_ptr(), uidx.data_ptr(), ucount.data_ptr(),
+                                        B, N, M, 4, 64, mlp, pk.wptr, pk.bptr, v32.data_ptr(), st), "crop fp32")
+    L.check(lib.gn_crop_unique_mlp_pool_split(xyz.data_ptr(), seed.data_ptr(), rot.data_ptr(), uidx.data_ptr(),
+                                              ucount.data_ptr(), B, N, M, 4, 64, mlp, pks.wptr, pks.bptr, vsp.data_ptr(), st),
+            "crop split")
+    torch.cuda.synchronize()
+    want = ref["_vp_features"].reshape(B, 256, M * 4).transpose(1, 2)
+    tru = truth["_vp_features"].reshape(B, 256, M * 4).transpose(1, 2)
+    e_or, e_32, e_sp = _errs(want, tru), _errs(v32, tru), _errs(vsp, tru)
+    print("crop features vs float64 (max, rms): oracle fp32 %s  fp32 MFMA %s  split bf16 %s" % (e_or, e_32, e_sp))
+    assert e_sp[0] <= 2.0 * max(e_or[0], e_32[0]) + 1e-6
+    assert e_sp[1] <= 2.0 * max(e_or[1], e_32[1]) + 1e-7
+    assert float((vsp - v32).abs().max()) <= 1e-4

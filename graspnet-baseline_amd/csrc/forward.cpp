@@ -129,14 +129,24 @@ extern "C" int gn_graspnet_forward(const gn_weights *wt, const float *cloud, int
       GN_STAGE(kBall[l], gn_ball_query(o->sa_xyz[l], lv_xyz, b, lv_n, c.npoint, c.radius, c.nsample, w.ball_idx[l], st));
     const float *const wp[3] = {wt->sa[l].w[0], wt->sa[l].w[1], wt->sa[l].w[2]};
     const float *const bp[3] = {wt->sa[l].b[0], wt->sa[l].b[1], wt->sa[l].b[2]};
+    const void *const wps[3] = {wt->sa_split[l].w[0], wt->sa_split[l].w[1], wt->sa_split[l].w[2]};
+    const float *const bps[3] = {wt->sa_split[l].b[0], wt->sa_split[l].b[1], wt->sa_split[l].b[2]};
     if (c.cin == 0) {
-      GN_STAGE(kSaName[l], gn_sa_group_mlp_pool(lv_xyz, nullptr, o->sa_xyz[l], w.ball_idx[l], b, lv_n, c.npoint,
-                                                c.nsample, 0, c.radius, c.mlp, wp, bp, o->sa_features[l], st));
+      if (wt->use_split)
+        GN_STAGE(kSaName[l], gn_sa_group_mlp_pool_split(lv_xyz, o->sa_xyz[l], w.ball_idx[l], b, lv_n, c.npoint, c.nsample,
+                                                        c.radius, c.mlp, wps, bps, o->sa_features[l], st));
+      else
+        GN_STAGE(kSaName[l], gn_sa_group_mlp_pool(lv_xyz, nullptr, o->sa_xyz[l], w.ball_idx[l], b, lv_n, c.npoint,
+                                                  c.nsample, 0, c.radius, c.mlp, wp, bp, o->sa_features[l], st));
     } else {
       GN_STAGE(kLin[l], gn_point_linear(lv_feat, b * lv_n, c.cin, c.mlp[0], wt->sa_pre[l].w[0], wt->sa_pre[l].b[0],
                                         w.pfeat[l], st));
-      GN_STAGE(kSaName[l], gn_sa_hoisted_mlp_pool(lv_xyz, w.pfeat[l], o->sa_xyz[l], w.ball_idx[l], b, lv_n, c.npoint,
-                                                  c.nsample, c.radius, c.mlp, wp, bp, o->sa_features[l], st));
+      if (wt->use_split)
+        GN_STAGE(kSaName[l], gn_sa_hoisted_mlp_pool_split(lv_xyz, w.pfeat[l], o->sa_xyz[l], w.ball_idx[l], b, lv_n, c.npoint,
+                                                          c.nsample, c.radius, c.mlp, wps, bps, o->sa_features[l], st));
+      else
+        GN_STAGE(kSaName[l], gn_sa_hoisted_mlp_pool(lv_xyz, w.pfeat[l], o->sa_xyz[l], w.ball_idx[l], b, lv_n, c.npoint,
+                                                    c.nsample, c.radius, c.mlp, wp, bp, o->sa_features[l], st));
     }
     lv_xyz = o->sa_xyz[l];
     lv_feat = o->sa_features[l];
@@ -184,8 +194,14 @@ extern "C" int gn_graspnet_forward(const gn_weights *wt, const float *cloud, int
       GN_STAGE("cylinder_query_unique",
                gn_cylinder_query_unique(seed_xyz, cloud, o->top_view_rot, b, n, M, wt->cylinder_radius, wt->hmin,
                                         wt->hmax, kDepths, kCropSamples, uidx, ucount, st));
-    GN_STAGE("crop_unique_mlp_pool", gn_crop_unique_mlp_pool(cloud, seed_xyz, o->top_view_rot, uidx, ucount, b, n, M, kDepths,
-                                                             kCropSamples, mlp, wp, bp, o->vp_features, st));
+    const void *const wps[3] = {wt->crop_split.w[0], wt->crop_split.w[1], wt->crop_split.w[2]};
+    const float *const bps[3] = {wt->crop_split.b[0], wt->crop_split.b[1], wt->crop_split.b[2]};
+    if (wt->use_split)
+      GN_STAGE("crop_unique_mlp_pool", gn_crop_unique_mlp_pool_split(cloud, seed_xyz, o->top_view_rot, uidx, ucount, b, n, M,
+                                                                     kDepths, kCropSamples, mlp, wps, bps, o->vp_features, st));
+    else
+      GN_STAGE("crop_unique_mlp_pool", gn_crop_unique_mlp_pool(cloud, seed_xyz, o->top_view_rot, uidx, ucount, b, n, M, kDepths,
+                                                               kCropSamples, mlp, wp, bp, o->vp_features, st));
   }
 
   // ---- OperationNet + ToleranceNet (modules.py:169-191, 214-232)

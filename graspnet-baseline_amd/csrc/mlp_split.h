@@ -191,16 +191,17 @@ __device__ __forceinline__ void interleave_step(int nreads, int nwrites) {
   }
 }
 
-// T orientation, one n-tile per wave: split + store of M tile t under the MFMAs of M tile t+1
+// T orientation, one n-tile per wave: split + store of this wave's M tile t under the MFMAs of its M tile t+1
+// (a quarter of the tile, 4 channels x this lane's position, behind every KB/4-th k-block)
 template <int TP, int CINP, int COUTP, int NWV = 4>
 __device__ __forceinline__ void run_layer_split_t_pipe(const LayerWS<CINP, COUTP, NWV> &w, const float (&bias_t)[16],
                                                        const __bf16 *__restrict__ xs, int xplane, int wave, int lane,
                                                        StoreSplit &epi, int mt_count = TP / 32) {
   using LW = LayerWS<CINP, COUTP, NWV>;
-  static_assert(LW::NTW == 1 && LW::WM == 1 && LW::KB == 4, "one n-tile per wave, every wave walks all M tiles, K = 64");
-  constexpr int XS = sp_stride(CINP), KB = LW::KB, MAXU = TP / 32;
-  const int wn = wave % LW::WN;
-  if (mt_count <= 0) return;
+  static_assert(LW::NTW == 1 && LW::KB % 4 == 0, "one n-tile per wave, K a multiple of 64");
+  constexpr int XS = sp_stride(CINP), KB = LW::KB, WM = LW::WM, MAXU = (TP / 32 + WM - 1) / WM, QS = KB / 4;
+  const int wm = wave / LW::WN, wn = wave % LW::WN;
+  if (wm >= mt_count) return;
   f32x16 acc[2];
   auto mma = [&](f32x16 &dst, int mt, auto &&fill) {
 #pragma unroll
@@ -218,13 +219,12 @@ __device__ __forceinline__ void run_layer_split_t_pipe(const LayerWS<CINP, COUTP
         for (int p = 0; p < 3; ++p) a[kb + 2][p] = *reinterpret_cast<const bf16x8 *>(xr + p * xplane + (kb + 2) * 16);
       }
       dst = mfma6<true>(a[kb], w.b[0][kb], dst);
-      fill(kb);
+      if (kb % QS == 0) fill(kb / QS);
       __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
       interleave_step<6>(3, 3);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  // one quarter (4 channels x this lane's position) of a finished tile
   auto store_quarter = [&](const f32x16 &src, int mt, int g) {
     __bf16 *row = epi.ys + (mt * 32 + (lane & 31)) * epi.stride + wn * 32 + 4 * (lane >> 5) + 8 * g;
     bf16x4 hi, mid, lo;
@@ -233,19 +233,20 @@ __device__ __forceinline__ void run_layer_split_t_pipe(const LayerWS<CINP, COUTP
     *reinterpret_cast<bf16x4 *>(row + epi.plane) = mid;
     *reinterpret_cast<bf16x4 *>(row + 2 * epi.plane) = lo;
   };
-  mma(acc[0], 0, [](int) {});
+  mma(acc[0], wm, [](int) {});
 #pragma unroll
   for (int u = 1; u < MAXU; ++u) {
-    if (u < mt_count) {
-      mma(acc[u & 1], u, [&](int kb) { store_quarter(acc[(u - 1) & 1], u - 1, kb); });
+    const int mt = wm + u * WM, pmt = wm + (u - 1) * WM;
+    if (mt < mt_count) {
+      mma(acc[u & 1], mt, [&](int q) { store_quarter(acc[(u - 1) & 1], pmt, q); });
     } else {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) store_quarter(acc[(u - 1) & 1], u - 1, g);
+      for (int g = 0; g < 4; ++g) store_quarter(acc[(u - 1) & 1], pmt, g);
       return;
     }
   }
 #pragma unroll
-  for (int g = 0; g < 4; ++g) store_quarter(acc[(MAXU - 1) & 1], MAXU - 1, g);
+  for (int g = 0; g < 4; ++g) store_quarter(acc[(MAXU - 1) & 1], wm + (MAXU - 1) * WM, g);
 }
 
 // N orientation with the masked-pool epilogue: unit = (M tile, n-tile of this wave); pooling of unit u (8 slices of two
@@ -345,6 +346,30 @@ __device__ __forceinline__ void run_layer_f32_t(const LayerW<8, COUTP, NWV> &w, 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = bias_t[r];
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(xs + (mt * 32 + (lane & 31)) * XS + 4 * (lane >> 5));
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.b[0][0][s], a[s], acc, 0, 0, 0);
+    epi(mt, wn, acc);
+  }
+}
+
+// the same with the accumulators starting from per-position rows gathered by the caller (the hoisted per-point part of
+// a set-abstraction layer 1, mlp_group.hip sa_hoist_kernel): c0[mi] holds, for this wave's mi-th M tile, the 16
+// accumulator rows (channels nt*32 + acc_row(r)) of this lane's position.
+template <int TP, int COUTP, int MTW, int NWV = 4>
+__device__ __forceinline__ void run_layer_f32_t_cinit(const LayerW<8, COUTP, NWV> &w, const f32x4 (&c0)[MTW][4],
+                                                      const float *__restrict__ xs, int wave, int lane, StoreSplit &epi) {
+  using LW = LayerW<8, COUTP, NWV>;
+  static_assert(LW::NTW == 1 && LW::WM == 1 && MTW == TP / 32, "one n-tile per wave, every wave walks all M tiles");
+  constexpr int XS = lds_stride(8);
+  const int wn = wave % LW::WN;
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) {
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[4 * g + j] = c0[mt][g][j];
     const f32x4 a = *reinterpret_cast<const f32x4 *>(xs + (mt * 32 + (lane & 31)) * XS + 4 * (lane >> 5));
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.b[0][0][s], a[s], acc, 0, 0, 0);

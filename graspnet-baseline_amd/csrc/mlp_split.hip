@@ -152,9 +152,256 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_unique_split_kernel(const fl
   GN_PROBE_FLUSH();
 }
 
+// ---- set abstraction, SA1 (no input features): SharedMLP[3,64,64,128] + max over 64 neighbours
+// (pointnet2_utils.py:344-355 + pointnet2_modules.py:251-257).  Layer 1 (K = 3) on the fp32 MFMA, layers 2-3 split.
+template <int C1, int C2, int C3, int NS>
+__global__ __launch_bounds__(MLP_THREADS) void sa_xyz_split_kernel(const float *__restrict__ xyz, int n,
+                                                                   const float *__restrict__ new_xyz,
+                                                                   const int32_t *__restrict__ idx, int np, int ntiles,
+                                                                   int tpb, float radius, SplitWeights W,
+                                                                   float *__restrict__ out) {
+  constexpr int TP = 128, GPT = TP / NS, XS0 = lds_stride(8);
+  constexpr int P1 = TP * sp_stride(C1), P2 = TP * sp_stride(C2);
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __bf16 *bufY1 = reinterpret_cast<__bf16 *>(smem_raw);     // 3 x [TP][C1+8]
+  __bf16 *bufY2 = bufY1 + 3 * P1;                           // 3 x [TP][C2+8]
+  float *bufX = reinterpret_cast<float *>(bufY2 + 3 * P2);  // 2 x [TP][12]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  using L1 = LayerW<8, C1>;
+  using L2 = LayerWS<C1, C2>;
+  using L3 = LayerWS<C2, C3>;
+  L1 w1;
+  L2 w2;
+  L3 w3;
+  w1.load(W.w1, W.b1, wave, lane);
+  w2.load(W.w2, wave, lane);
+  w3.load(W.w3, wave, lane);
+  float b1t[16], b2t[16], b3[L3::NTW];
+  load_bias_t(W.b1, wave % L1::WN, lane, b1t);
+  load_bias_t(W.b2, wave % L2::WN, lane, b2t);
+#pragma unroll
+  for (int i = 0; i < L3::NTW; ++i) b3[i] = W.b3[((wave % L3::WN) * L3::NTW + i) * 32 + (lane & 31)];
+  const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * tpb);
+  int tile = blockIdx.x * tpb;
+  if (tile >= tile_end) return;
+  auto fetch_x = [&](int tl, f32x4 &v) {
+    const int g0 = tl * GPT;
+    const int b = g0 / np;
+    v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < TP) {
+      const int src = idx[(size_t)g0 * NS + tid];
+      const float *c = new_xyz + ((size_t)g0 + tid / NS) * 3;
+      const float *px = xyz + (size_t)b * n * 3;
+      v[0] = (px[src * 3 + 0] - c[0]) / radius;   // pointnet2_utils.py:346-348
+      v[1] = (px[src * 3 + 1] - c[1]) / radius;
+      v[2] = (px[src * 3 + 2] - c[2]) / radius;
+    }
+  };
+  auto put_x = [&](int buf, const f32x4 &v) {
+    if (tid < TP) {
+      float *x = bufX + buf * TP * XS0 + tid * XS0;
+      *reinterpret_cast<f32x4 *>(x) = v;
+      *reinterpret_cast<f32x4 *>(x + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  int buf = 0;
+  {
+    f32x4 v;
+    fetch_x(tile, v);
+    put_x(0, v);
+  }
+  __syncthreads();
+  for (; tile < tile_end; ++tile) {
+    const int g0 = tile * GPT;
+    const bool has_next = tile + 1 < tile_end;
+    f32x4 nv;
+    if (has_next) fetch_x(tile + 1, nv);          // in flight under the three layers
+    StoreSplit e1{bufY1, sp_stride(C1), P1, lane};
+    run_layer_f32_t<TP, C1>(w1, b1t, bufX + buf * TP * XS0, wave, lane, e1);
+    __syncthreads();
+    StoreSplit e2{bufY2, sp_stride(C2), P2, lane};
+    run_layer_split_t_pipe<TP, C1, C2>(w2, b2t, bufY1, P1, wave, lane, e2);
+    __syncthreads();
+    PoolGlobal<NS, L3::NTW> e3{out + (size_t)g0 * C3, C3, lane, {}};
+    run_layer_split_n<TP, C2, C3>(w3, b3, bufY2, P2, wave, lane, e3);
+    if (has_next) put_x(buf ^ 1, nv);
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+// ---- set abstraction with layer 1's per-point part hoisted (gn_point_linear), SA2-SA4: the gathered P rows are
+// the fp32 accumulators' initial value (each lane fetches exactly the 4 x float4 it needs per M tile, no LDS staging),
+// the K = 8 coordinate block runs on the fp32 MFMA, layers 2-3 split.  TP = 64 (three bf16 planes of 128 channels).
+template <int C1, int C2, int C3, int NS>
+__global__ __launch_bounds__(MLP_THREADS) void sa_hoist_split_kernel(const float *__restrict__ xyz, int n,
+                                                                     const float *__restrict__ pfeat,
+                                                                     const float *__restrict__ new_xyz,
+                                                                     const int32_t *__restrict__ idx, int np, int ntiles,
+                                                                     int tpb, float radius, SplitWeights W,
+                                                                     float *__restrict__ out) {
+  constexpr int TP = 64, MT = TP / 32, GPT = TP / NS, XS0 = lds_stride(8);
+  constexpr int P1 = TP * sp_stride(C1), P2 = TP * sp_stride(C2);
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __bf16 *bufY1 = reinterpret_cast<__bf16 *>(smem_raw);     // 3 x [TP][C1+8]
+  __bf16 *bufY2 = bufY1 + 3 * P1;                           // 3 x [TP][C2+8]
+  float *bufX = reinterpret_cast<float *>(bufY2 + 3 * P2);  // 2 x [TP][12]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  using L1 = LayerW<8, C1>;
+  using L2 = LayerWS<C1, C2>;
+  using L3 = LayerWS<C2, C3>;
+  static_assert(L1::WN == 4 && L1::WM == 1, "layer 1: one n-tile per wave");
+  L1 w1;
+  L2 w2;
+  L3 w3;
+  w1.load(W.w1, W.b1, wave, lane);
+  w2.load(W.w2, wave, lane);
+  w3.load(W.w3, wave, lane);
+  float b2t[16], b3[L3::NTW];
+  load_bias_t(W.b2, wave % L2::WN, lane, b2t);
+#pragma unroll
+  for (int i = 0; i < L3::NTW; ++i) b3[i] = W.b3[((wave % L3::WN) * L3::NTW + i) * 32 + (lane & 31)];
+  const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * tpb);
+  int tile = blockIdx.x * tpb;
+  if (tile >= tile_end) return;
+
+  // this lane's accumulator-initial rows of tile tl: position mt*32 + (lane&31), channels wave*32 + 8g + 4(lane>>5) ..+3
+  auto fetch_p = [&](int tl, f32x4 (&pf)[MT][4]) {
+    const int g0 = tl * GPT;
+    const int b = g0 / np;
+    const int32_t *ix = idx + (size_t)g0 * NS;
+    const float *pb = pfeat + (size_t)b * n * C1 + wave * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const float *row = pb + (size_t)ix[mt * 32 + (lane & 31)] * C1;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pf[mt][g] = *reinterpret_cast<const f32x4 *>(row + 8 * g);
+    }
+  };
+  auto fetch_x = [&](int tl, f32x4 &v) {
+    const int g0 = tl * GPT;
+    const int b = g0 / np;
+    v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < TP) {
+      const int src = idx[(size_t)g0 * NS + tid];
+      const float *c = new_xyz + ((size_t)g0 + tid / NS) * 3;
+      const float *px = xyz + (size_t)b * n * 3;
+      v[0] = (px[src * 3 + 0] - c[0]) / radius;   // pointnet2_utils.py:346-348
+      v[1] = (px[src * 3 + 1] - c[1]) / radius;
+      v[2] = (px[src * 3 + 2] - c[2]) / radius;
+    }
+  };
+  auto put_x = [&](int buf, const f32x4 &v) {
+    if (tid < TP) {
+      float *x = bufX + buf * TP * XS0 + tid * XS0;
+      *reinterpret_cast<f32x4 *>(x) = v;
+      *reinterpret_cast<f32x4 *>(x + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  int buf = 0;
+  f32x4 pf[MT][4];
+  {
+    f32x4 v;
+    fetch_p(tile, pf);
+    fetch_x(tile, v);
+    put_x(0, v);
+  }
+  __syncthreads();
+  for (; tile < tile_end; ++tile) {
+    const int g0 = tile * GPT;
+    const bool has_next = tile + 1 < tile_end;
+    StoreSplit e1{bufY1, sp_stride(C1), P1, lane};
+    run_layer_f32_t_cinit<TP, C1, MT>(w1, pf, bufX + buf * TP * XS0, wave, lane, e1);
+    f32x4 nv;
+    if (has_next) { fetch_p(tile + 1, pf); fetch_x(tile + 1, nv); }   // in flight under layers 2-3
+    __syncthreads();
+    StoreSplit e2{bufY2, sp_stride(C2), P2, lane};
+    run_layer_split_t_pipe<TP, C1, C2>(w2, b2t, bufY1, P1, wave, lane, e2);
+    __syncthreads();
+    PoolGlobal<NS, L3::NTW> e3{out + (size_t)g0 * C3, C3, lane, {}};
+    run_layer_split_n<TP, C2, C3>(w3, b3, bufY2, P2, wave, lane, e3);
+    if (has_next) put_x(buf ^ 1, nv);
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
 }  // namespace gn
 
 using namespace gn;
+
+static int split_tiles_per_block(int ntiles) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  int tpb = ntiles / (cus * 4);
+  return tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
+}
+
+extern "C" int gn_sa_group_mlp_pool_split(const float *xyz, const float *new_xyz, const int32_t *idx, int b, int n, int np,
+                                          int ns, float radius, const int *mlp, const void *const *wpacked,
+                                          const float *const *bias, float *out, gn_stream_t stream) {
+  GN_REQUIRE(b >= 0 && n > 0 && np > 0 && ns > 0, "sa_group_mlp_pool_split: bad sizes");
+  if (b == 0) return GN_OK;
+  GN_REQUIRE(xyz && new_xyz && idx && mlp && wpacked && bias && out, "sa_group_mlp_pool_split: null pointer");
+  GN_REQUIRE((long)n * 3 < 0x7fffffffL, "sa_group_mlp_pool_split: n too large");
+  if (!(mlp[0] == 64 && mlp[1] == 64 && mlp[2] == 128 && ns == 64)) {
+    set_error("sa_group_mlp_pool_split: unsupported configuration mlp=[%d,%d,%d] nsample=%d", mlp[0], mlp[1], mlp[2], ns);
+    return GN_ERR_INVALID_ARG;
+  }
+  constexpr int TP = 128;
+  GN_REQUIRE(np % (TP / 64) == 0, "sa_group_mlp_pool_split: npoint must be even");
+  const SplitWeights W{static_cast<const float *>(wpacked[0]), bias[0], wpacked[1], wpacked[2], bias[1], bias[2]};
+  const int ntiles = (int)((long)b * np / (TP / ns));
+  constexpr size_t lds = 2 * (3 * TP * sp_stride(64) + 3 * TP * sp_stride(64)) + sizeof(float) * (2 * TP * lds_stride(8));
+  auto k = sa_xyz_split_kernel<64, 64, 128, 64>;
+  int rc;
+  if ((rc = set_lds_attr(k, lds, "sa_group_mlp_pool_split"))) return rc;
+  const int tpb = split_tiles_per_block(ntiles);
+  hipLaunchKernelGGL(k, dim3((ntiles + tpb - 1) / tpb), dim3(MLP_THREADS), lds, as_stream(stream), xyz, n, new_xyz, idx, np,
+                     ntiles, tpb, radius, W, out);
+  GN_CHECK_LAUNCH("sa_group_mlp_pool_split");
+  return GN_OK;
+}
+
+extern "C" int gn_sa_hoisted_mlp_pool_split(const float *xyz, const float *pfeat, const float *new_xyz, const int32_t *idx,
+                                            int b, int n, int np, int ns, float radius, const int *mlp,
+                                            const void *const *wpacked, const float *const *bias, float *out,
+                                            gn_stream_t stream) {
+  GN_REQUIRE(b >= 0 && n > 0 && np > 0 && ns > 0, "sa_hoisted_mlp_pool_split: bad sizes");
+  if (b == 0) return GN_OK;
+  GN_REQUIRE(xyz && pfeat && new_xyz && idx && mlp && wpacked && bias && out, "sa_hoisted_mlp_pool_split: null pointer");
+  GN_REQUIRE((long)n * 128 < 0x7fffffffL, "sa_hoisted_mlp_pool_split: n too large");
+  if (!(mlp[0] == 128 && mlp[1] == 128 && mlp[2] == 256 && (ns == 32 || ns == 16))) {
+    set_error("sa_hoisted_mlp_pool_split: unsupported configuration mlp=[%d,%d,%d] nsample=%d", mlp[0], mlp[1], mlp[2], ns);
+    return GN_ERR_INVALID_ARG;
+  }
+  constexpr int TP = 64;
+  GN_REQUIRE(np % (TP / ns) == 0, "sa_hoisted_mlp_pool_split: npoint must be a multiple of %d", TP / ns);
+  const SplitWeights W{static_cast<const float *>(wpacked[0]), bias[0], wpacked[1], wpacked[2], bias[1], bias[2]};
+  const int ntiles = (int)((long)b * np / (TP / ns));
+  constexpr size_t lds = 2 * (3 * TP * sp_stride(128) + 3 * TP * sp_stride(128)) + sizeof(float) * (2 * TP * lds_stride(8));
+  const int tpb = split_tiles_per_block(ntiles);
+  int rc;
+  if (ns == 32) {
+    auto k = sa_hoist_split_kernel<128, 128, 256, 32>;
+    if ((rc = set_lds_attr(k, lds, "sa_hoisted_mlp_pool_split"))) return rc;
+    hipLaunchKernelGGL(k, dim3((ntiles + tpb - 1) / tpb), dim3(MLP_THREADS), lds, as_stream(stream), xyz, n, pfeat, new_xyz,
+                       idx, np, ntiles, tpb, radius, W, out);
+  } else {
+    auto k = sa_hoist_split_kernel<128, 128, 256, 16>;
+    if ((rc = set_lds_attr(k, lds, "sa_hoisted_mlp_pool_split"))) return rc;
+    hipLaunchKernelGGL(k, dim3((ntiles + tpb - 1) / tpb), dim3(MLP_THREADS), lds, as_stream(stream), xyz, n, pfeat, new_xyz,
+                       idx, np, ntiles, tpb, radius, W, out);
+  }
+  GN_CHECK_LAUNCH("sa_hoisted_mlp_pool_split");
+  return GN_OK;
+}
 
 extern "C" int gn_crop_unique_mlp_pool_split(const float *xyz, const float *seed_xyz, const float *rot, const int32_t *uidx,
                                              const int32_t *ucount, int b, int n, int m, int ndepth, int ns, const int *mlp,

@@ -27,7 +27,8 @@ class MlpWeights(ctypes.Structure):          # gn_mlp_weights
 class Weights(ctypes.Structure):             # gn_weights
     _fields_ = [("sa", MlpWeights * 4), ("sa_pre", MlpWeights * 4), ("fp", MlpWeights * 2), ("approach", MlpWeights),
                 ("crop", MlpWeights), ("heads", MlpWeights), ("views", _c_void_p), ("view_rot", _c_void_p),
-                ("decode_rot", _c_void_p), ("cylinder_radius", _c_float), ("hmin", _c_float), ("hmax", _c_float * 4)]
+                ("decode_rot", _c_void_p), ("cylinder_radius", _c_float), ("hmin", _c_float), ("hmax", _c_float * 4),
+                ("use_split", _c_int), ("sa_split", MlpWeights * 4), ("crop_split", MlpWeights)]
 
 
 class Outputs(ctypes.Structure):             # gn_outputs
@@ -72,6 +73,12 @@ SIGNATURES = {
     "gn_crop_unique_mlp_pool_split": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                                _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_void_p),
                                                ctypes.POINTER(_c_void_p), _c_void_p, _c_void_p]),
+    "gn_sa_group_mlp_pool_split": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_float,
+                                            ctypes.POINTER(_c_int), ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
+                                            _c_void_p, _c_void_p]),
+    "gn_sa_hoisted_mlp_pool_split": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                                              _c_float, ctypes.POINTER(_c_int), ctypes.POINTER(_c_void_p),
+                                              ctypes.POINTER(_c_void_p), _c_void_p, _c_void_p]),
     "gn_sa_group_mlp_pool": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                       _c_float, ctypes.POINTER(_c_int), ctypes.POINTER(_c_void_p),
                                       ctypes.POINTER(_c_void_p), _c_void_p, _c_void_p]),

@@ -64,8 +64,9 @@ class GraspNet:
         # forward); GN_FORWARD=stages issues the same stage calls one by one from here (always used for the
         # non-default A/B paths above)
         self.native_forward = os.environ.get("GN_FORWARD", "native") != "stages"
-        # layers on the bf16 matrix cores by exact operand splitting (csrc/mlp_split.h) instead of the fp32 MFMA
-        self.math_split = os.environ.get("GN_MATH", "f32") == "split"
+        # grouped layers on the bf16 matrix cores by exact operand splitting (csrc/mlp_split.h; as accurate as fp32,
+        # 1.5-1.6x faster kernels) or on the fp32 MFMA (GN_MATH=f32)
+        self.math_split = os.environ.get("GN_MATH", "split") != "f32"
 
     def _run(self, name, status_fn):
         """Issue one C-ABI call; when self.timing is a dict, bracket it with events on the launch stream."""
@@ -140,6 +141,11 @@ class GraspNet:
         w.cylinder_radius, w.hmin = self.cylinder_radius, self.hmin
         for i in range(4):
             w.hmax[i] = self.hmax[i]
+        fill(w.sa_split[0], pk["sa1_split"])
+        for l in (1, 2, 3):
+            fill(w.sa_split[l], pk["sa%d_hoist_split" % (l + 1)])
+        fill(w.crop_split, pk["crop_split"])
+        w.use_split = 1 if self.math_split else 0
         return w
 
     def _forward_native(self, end_points, xyz):
@@ -183,6 +189,7 @@ class GraspNet:
                     self.timing.setdefault(name.decode(), []).append((pending.pop(name), ev))
             hook = L.STAGE_HOOK(on_stage)
         st = torch.cuda.current_stream(dev).cuda_stream
+        self._cweights.use_split = 1 if self.math_split else 0
         L.check(lib.gn_graspnet_forward(ctypes.byref(self._cweights), xyz.data_ptr(), B, N, ws.data_ptr(),
                                         ctypes.byref(o), hook, None, st), "graspnet_forward")
         for li in range(4):
@@ -230,8 +237,7 @@ class GraspNet:
             xyz = pc[..., 0:3].contiguous()                      # backbone.py:69-75 _break_up_pc
             end_points["input_xyz"] = xyz
             end_points["input_features"] = None
-            if (self.native_forward and self.crop_unique and self.sa_hoist and self.query_grid and not self.math_split
-                    and N >= SA_CFG[0][0]):
+            if self.native_forward and self.crop_unique and self.sa_hoist and self.query_grid and N >= SA_CFG[0][0]:
                 return self._forward_native(end_points, xyz)
 
             # ---- 4 set-abstraction levels (backbone.py:105-121)
@@ -269,9 +275,20 @@ class GraspNet:
                     self._run("point_linear[%d]" % (li + 1), lambda: lib.gn_point_linear(
                         lv_feat.data_ptr(), B * lv_n, c, mlp[0], pre.w[0].data_ptr(), pre.b[0].data_ptr(),
                         pfeat.data_ptr(), st))
-                    self._run("sa_hoisted_mlp_pool[%d]" % (li + 1), lambda: lib.gn_sa_hoisted_mlp_pool(
-                        lv_xyz.data_ptr(), pfeat.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), B, lv_n, npoint, nsample,
-                        radius, _ci(*mlp), pk.wptr, pk.bptr, out.data_ptr(), st))
+                    if self.math_split:
+                        pks = self._packed["sa%d_hoist_split" % (li + 1)]
+                        self._run("sa_hoisted_mlp_pool[%d]" % (li + 1), lambda: lib.gn_sa_hoisted_mlp_pool_split(
+                            lv_xyz.data_ptr(), pfeat.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), B, lv_n, npoint,
+                            nsample, radius, _ci(*mlp), pks.wptr, pks.bptr, out.data_ptr(), st))
+                    else:
+                        self._run("sa_hoisted_mlp_pool[%d]" % (li + 1), lambda: lib.gn_sa_hoisted_mlp_pool(
+                            lv_xyz.data_ptr(), pfeat.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), B, lv_n, npoint,
+                            nsample, radius, _ci(*mlp), pk.wptr, pk.bptr, out.data_ptr(), st))
+                elif c == 0 and self.math_split:
+                    pks = self._packed["sa1_split"]
+                    self._run("sa_group_mlp_pool[1]", lambda: lib.gn_sa_group_mlp_pool_split(
+                        lv_xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), B, lv_n, npoint, nsample, radius, _ci(*mlp),
+                        pks.wptr, pks.bptr, out.data_ptr(), st))
                 else:
                     pk = self._packed["sa%d" % (li + 1)]
                     self._run("sa_group_mlp_pool[%d]" % (li + 1), lambda: lib.gn_sa_group_mlp_pool(

@@ -100,12 +100,16 @@ def prepare(sd, device, num_view=300, num_angle=12):
         w0 = torch.cat([w0[:, 3:], w0[:, :3]], dim=1)
         packed = [pack_fragments(w0, b0, cinp=c + 8)] + [pack_fragments(w, b) for w, b in layers[1:]]
         out["sa%d" % (li + 1)] = PackedMlp(packed, device)
+        if c == 0:   # SA1 on the matrix-core path: layer 1 (K = 3) fp32, layers 2-3 split
+            out["sa1_split"] = PackedMlp([pack_fragments(w0, b0, cinp=8)] + [pack_split(w, b) for w, b in layers[1:]], device)
         if c > 0:
             # layer 1 split for the hoisted kernel: per-point part W1f (+ bias) and per-neighbour K=8 block W1x
             out["sa%d_pre" % (li + 1)] = PackedMlp([pack_fragments(w0[:, :c], b0)], device)
             out["sa%d_hoist" % (li + 1)] = PackedMlp(
                 [pack_fragments(w0[:, c:], torch.zeros_like(b0), cinp=8)] + [pack_fragments(w, b) for w, b in layers[1:]],
                 device)
+            out["sa%d_hoist_split" % (li + 1)] = PackedMlp(
+                [pack_fragments(w0[:, c:], torch.zeros_like(b0), cinp=8)] + [pack_split(w, b) for w, b in layers[1:]], device)
     for i in (1, 2):
         layers = _shared_mlp_layers(sd, "%s.fp%d.mlp" % (bb, i), 2)
         out["fp%d" % i] = PackedMlp([pack_fragments(w, b) for w, b in layers], device)

@@ -215,6 +215,17 @@ int gn_crop_unique_mlp_pool_split(const float *xyz, const float *seed_xyz, const
                                   const void *const *wpacked, const float *const *bias, float *out,
                                   gn_stream_t stream);
 
+/* Set-abstraction tails with layers 2-3 on the bf16 matrix cores (same splitting as above; wpacked[0] fp32 fragments of
+ * layer 1 -- for the hoisted form its K=8 coordinate block with zero bias --, wpacked[1..2] split fragments).
+ * gn_sa_group_mlp_pool_split: SA1 only (no input features, mlp {64,64,128}, nsample 64).
+ * gn_sa_hoisted_mlp_pool_split: SA2-SA4 (mlp {128,128,256}, nsample 32 or 16), pfeat from gn_point_linear. */
+int gn_sa_group_mlp_pool_split(const float *xyz, const float *new_xyz, const int32_t *idx, int b, int n, int np, int ns,
+                               float radius, const int *mlp, const void *const *wpacked, const float *const *bias,
+                               float *out, gn_stream_t stream);
+int gn_sa_hoisted_mlp_pool_split(const float *xyz, const float *pfeat, const float *new_xyz, const int32_t *idx, int b,
+                                 int n, int np, int ns, float radius, const int *mlp, const void *const *wpacked,
+                                 const float *const *bias, float *out, gn_stream_t stream);
+
 /* PointnetFPModule tail (pointnet2_modules.py:395-416): inverse-distance weights from three_nn's
  * dist2/idx, three_interpolate, concat skip features, SharedMLP(2 layers).
  * known_feat (B,m,ck), skip_feat (B,n,cs) channels-last -> out (B,n,mlp[1]). */
@@ -270,6 +281,11 @@ typedef struct gn_weights {
   const float *view_rot;     /* (300,9)  rotation of each template view, in-plane angle 0 */
   const float *decode_rot;   /* (300*12,9) rotation of (-view, angle class) used by pred_decode */
   float cylinder_radius, hmin, hmax[4];
+  /* matrix-core path (csrc/mlp_split.h): when use_split != 0 the grouped layers run from these instead of sa[] / crop:
+   * w[0] fp32 fragments of layer 1 (hoisted levels: the K=8 coordinate block), w[1..2] split-bf16 fragments */
+  int use_split;
+  gn_mlp_weights sa_split[4];
+  gn_mlp_weights crop_split;
 } gn_weights;
 
 typedef struct gn_outputs {          /* device buffers owned by the caller; all required unless noted */

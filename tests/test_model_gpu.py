@@ -254,9 +254,12 @@ def test_sa_hoisted_equals_plain(net, state_dict, clouds):
     from graspnet_amd import GraspNet
     plain = GraspNet().load_state_dict(state_dict)
     plain.sa_hoist = False
-    a = net({"point_clouds": clouds.cuda()})
+    plain.math_split = False
+    hoisted = GraspNet().load_state_dict(state_dict)
+    hoisted.math_split = False             # the fp32 MFMA kernels: same k order with and without hoisting
+    a = hoisted({"point_clouds": clouds.cuda()})
     b = plain({"point_clouds": clouds.cuda()})
-    assert net.sa_hoist and not plain.sa_hoist
+    assert hoisted.sa_hoist and not plain.sa_hoist
     for k in ("sa1_features", "sa2_features", "sa3_features", "sa4_features", "fp2_features", "grasp_score_pred"):
         assert torch.equal(a[k], b[k]), k
 
@@ -301,15 +304,22 @@ def test_pred_decode_isolated_exact(ref, net):
         assert torch.equal(a[:, 3].cpu(), b[:, 3]) and torch.equal(a[:, 13:16].cpu(), b[:, 13:16])
 
 
-def test_end_to_end_grasps(hip, ref):
-    """Full fused path vs oracle: rows matched by seed; score within 1e-4 where no discrete flip."""
+def test_end_to_end_grasps(hip, ref, truth, model_oracle):
+    """Full fused path vs oracle: rows matched by seed.  The raw network scores are held to 1e-4 elsewhere
+    (test_backbone_features / test_approach_scores / test_crop_and_heads); the DECODED score is
+    score * tolerance / 0.05 (graspnet.py:121), a product of two fp32 outputs times 20, and even the fp32 CPU oracle
+    sits ~2e-4 from a float64 evaluation of it (profiles/score_err_probe.py).  So the decoded score is judged like the
+    features: error against float64 within 2x of the oracle's own, and within 3e-4 + 1e-4 relative of the oracle."""
     _, preds = hip
     rep, rpreds = ref
+    tpreds = model_oracle.pred_decode(truth)
     tot = flips = 0
-    for b, (a, r) in enumerate(zip(preds, rpreds)):
+    err_hip = err_or = 0.0
+    for b, (a, r, t) in enumerate(zip(preds, rpreds, tpreds)):
         a = a.cpu()
         ka = {tuple(row[13:16].tolist()): row for row in a}
         kr = {tuple(row[13:16].tolist()): row for row in r}
+        kt = {tuple(row[13:16].float().tolist()): row for row in t}
         common = set(ka) & set(kr)
         # objectness flips change membership; must be rare
         assert len(set(ka) ^ set(kr)) <= 4, "objectness flips: %d" % len(set(ka) ^ set(kr))
@@ -319,10 +329,15 @@ def test_end_to_end_grasps(hip, ref):
             if not torch.allclose(x[4:13], y[4:13], atol=1e-5) or x[3] != y[3]:
                 flips += 1            # view / angle / depth class flipped on a near-tie
                 continue
-            assert abs(float(x[0] - y[0])) <= 1e-4 + 1e-4 * abs(float(y[0])), (b, key, float(x[0]), float(y[0]))
+            assert abs(float(x[0] - y[0])) <= 3e-4 + 1e-4 * abs(float(y[0])), (b, key, float(x[0]), float(y[0]))
             assert abs(float(x[1] - y[1])) <= 1e-5
+            z = kt.get(key)
+            if z is not None and torch.allclose(z[4:13].float(), y[4:13], atol=1e-5) and float(z[3]) == float(y[3]):
+                err_hip = max(err_hip, abs(float(x[0]) - float(z[0])))
+                err_or = max(err_or, abs(float(y[0]) - float(z[0])))
     assert tot > 1000
     assert flips <= max(4, tot // 200), "class flips %d of %d" % (flips, tot)
+    assert err_or > 0 and err_hip <= 2.0 * err_or + 1e-5, "decoded score vs float64: hip %.3e oracle %.3e" % (err_hip, err_or)
 
 
 def test_against_golden_samples(hip, golden_dir):

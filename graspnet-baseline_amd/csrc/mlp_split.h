@@ -154,23 +154,22 @@ __device__ __forceinline__ void run_layer_split_n(const LayerWS<CINP, COUTP, NWV
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = bias[i];
     const __bf16 *xr = xs + (mt * 32 + (lane & 31)) * XS + 8 * (lane >> 5);
+    // operands two k-blocks ahead of their MFMAs; a sched_barrier per k-block keeps the window at three blocks
+    // (hipcc otherwise hoists all KB*3 fragment reads: 96 registers at K = 128)
     bf16x8 a[KB][3];
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
+    for (int kb = 0; kb < (KB < 2 ? KB : 2); ++kb)
 #pragma unroll
       for (int p = 0; p < 3; ++p) a[kb][p] = *reinterpret_cast<const bf16x8 *>(xr + p * xplane + kb * 16);
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
+    for (int kb = 0; kb < KB; ++kb) {
+      if (kb + 2 < KB) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[kb + 2][p] = *reinterpret_cast<const bf16x8 *>(xr + p * xplane + (kb + 2) * 16);
+      }
 #pragma unroll
       for (int i = 0; i < NTW; ++i) acc[i] = mfma6<false>(a[kb], w.b[i][kb], acc[i]);
-    if constexpr (KB > 2) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-#pragma unroll
-      for (int kb = 0; kb < KB - 2; ++kb) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 6 * NTW, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 12 * NTW, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int i = 0; i < NTW; ++i) epi(mt, wn * NTW + i, i, acc[i]);
@@ -354,22 +353,23 @@ __device__ __forceinline__ void run_layer_f32_t(const LayerW<8, COUTP, NWV> &w, 
 }
 
 // the same with the accumulators starting from per-position rows gathered by the caller (the hoisted per-point part of
-// a set-abstraction layer 1, mlp_group.hip sa_hoist_kernel): c0[mi] holds, for this wave's mi-th M tile, the 16
-// accumulator rows (channels nt*32 + acc_row(r)) of this lane's position.
+// a set-abstraction layer 1, mlp_group.hip sa_hoist_kernel): c0[mi] holds, for this wave's mi-th M tile (wm + mi*WM),
+// the 16 accumulator rows (channels nt*32 + acc_row(r)) of this lane's position.
 template <int TP, int COUTP, int MTW, int NWV = 4>
 __device__ __forceinline__ void run_layer_f32_t_cinit(const LayerW<8, COUTP, NWV> &w, const f32x4 (&c0)[MTW][4],
                                                       const float *__restrict__ xs, int wave, int lane, StoreSplit &epi) {
   using LW = LayerW<8, COUTP, NWV>;
-  static_assert(LW::NTW == 1 && LW::WM == 1 && MTW == TP / 32, "one n-tile per wave, every wave walks all M tiles");
+  static_assert(LW::NTW == 1 && MTW * LW::WM == TP / 32, "one n-tile per wave, M tiles divide over the wave rows");
   constexpr int XS = lds_stride(8);
-  const int wn = wave % LW::WN;
+  const int wm = wave / LW::WN, wn = wave % LW::WN;
 #pragma unroll
-  for (int mt = 0; mt < MTW; ++mt) {
+  for (int mi = 0; mi < MTW; ++mi) {
+    const int mt = wm + mi * LW::WM;
     f32x16 acc;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[4 * g + j] = c0[mt][g][j];
+      for (int j = 0; j < 4; ++j) acc[4 * g + j] = c0[mi][g][j];
     const f32x4 a = *reinterpret_cast<const f32x4 *>(xs + (mt * 32 + (lane & 31)) * XS + 4 * (lane >> 5));
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.b[0][0][s], a[s], acc, 0, 0, 0);

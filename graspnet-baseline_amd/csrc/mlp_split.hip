@@ -154,13 +154,14 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_unique_split_kernel(const fl
 
 // ---- set abstraction, SA1 (no input features): SharedMLP[3,64,64,128] + max over 64 neighbours
 // (pointnet2_utils.py:344-355 + pointnet2_modules.py:251-257).  Layer 1 (K = 3) on the fp32 MFMA, layers 2-3 split.
-template <int C1, int C2, int C3, int NS>
-__global__ __launch_bounds__(MLP_THREADS) void sa_xyz_split_kernel(const float *__restrict__ xyz, int n,
+template <int C1, int C2, int C3, int NS, int TP, int MINW>
+__global__ __launch_bounds__(MLP_THREADS, MINW) void sa_xyz_split_kernel(const float *__restrict__ xyz, int n,
                                                                    const float *__restrict__ new_xyz,
                                                                    const int32_t *__restrict__ idx, int np, int ntiles,
                                                                    int tpb, float radius, SplitWeights W,
                                                                    float *__restrict__ out) {
-  constexpr int TP = 128, GPT = TP / NS, XS0 = lds_stride(8);
+  constexpr int GPT = TP / NS, XS0 = lds_stride(8);
+  static_assert(GPT >= 1, "a tile holds whole groups");
   constexpr int P1 = TP * sp_stride(C1), P2 = TP * sp_stride(C2);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __bf16 *bufY1 = reinterpret_cast<__bf16 *>(smem_raw);     // 3 x [TP][C1+8]
@@ -233,8 +234,8 @@ __global__ __launch_bounds__(MLP_THREADS) void sa_xyz_split_kernel(const float *
 // ---- set abstraction with layer 1's per-point part hoisted (gn_point_linear), SA2-SA4: the gathered P rows are
 // the fp32 accumulators' initial value (each lane fetches exactly the 4 x float4 it needs per M tile, no LDS staging),
 // the K = 8 coordinate block runs on the fp32 MFMA, layers 2-3 split.  TP = 64 (three bf16 planes of 128 channels).
-template <int C1, int C2, int C3, int NS>
-__global__ __launch_bounds__(MLP_THREADS) void sa_hoist_split_kernel(const float *__restrict__ xyz, int n,
+template <int C1, int C2, int C3, int NS, int NWV>
+__global__ __launch_bounds__(NWV * 64) void sa_hoist_split_kernel(const float *__restrict__ xyz, int n,
                                                                      const float *__restrict__ pfeat,
                                                                      const float *__restrict__ new_xyz,
                                                                      const int32_t *__restrict__ idx, int np, int ntiles,
@@ -247,10 +248,11 @@ __global__ __launch_bounds__(MLP_THREADS) void sa_hoist_split_kernel(const float
   __bf16 *bufY2 = bufY1 + 3 * P1;                           // 3 x [TP][C2+8]
   float *bufX = reinterpret_cast<float *>(bufY2 + 3 * P2);  // 2 x [TP][12]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  using L1 = LayerW<8, C1>;
-  using L2 = LayerWS<C1, C2>;
-  using L3 = LayerWS<C2, C3>;
-  static_assert(L1::WN == 4 && L1::WM == 1, "layer 1: one n-tile per wave");
+  using L1 = LayerW<8, C1, NWV>;
+  using L2 = LayerWS<C1, C2, NWV>;
+  using L3 = LayerWS<C2, C3, NWV>;
+  static_assert(L1::WN == 4 && MT % L1::WM == 0, "layer 1: one n-tile per wave, M tiles divide over the wave rows");
+  constexpr int MTW = MT / L1::WM;
   L1 w1;
   L2 w2;
   L3 w3;
@@ -266,16 +268,16 @@ __global__ __launch_bounds__(MLP_THREADS) void sa_hoist_split_kernel(const float
   if (tile >= tile_end) return;
 
   // this lane's accumulator-initial rows of tile tl: position mt*32 + (lane&31), channels wave*32 + 8g + 4(lane>>5) ..+3
-  auto fetch_p = [&](int tl, f32x4 (&pf)[MT][4]) {
+  auto fetch_p = [&](int tl, f32x4 (&pf)[MTW][4]) {
     const int g0 = tl * GPT;
     const int b = g0 / np;
     const int32_t *ix = idx + (size_t)g0 * NS;
-    const float *pb = pfeat + (size_t)b * n * C1 + wave * 32 + 4 * (lane >> 5);
+    const float *pb = pfeat + (size_t)b * n * C1 + (wave % L1::WN) * 32 + 4 * (lane >> 5);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const float *row = pb + (size_t)ix[mt * 32 + (lane & 31)] * C1;
+    for (int mi = 0; mi < MTW; ++mi) {
+      const float *row = pb + (size_t)ix[(wave / L1::WN + mi * L1::WM) * 32 + (lane & 31)] * C1;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) pf[mt][g] = *reinterpret_cast<const f32x4 *>(row + 8 * g);
+      for (int g = 0; g < 4; ++g) pf[mi][g] = *reinterpret_cast<const f32x4 *>(row + 8 * g);
     }
   };
   auto fetch_x = [&](int tl, f32x4 &v) {
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(MLP_THREADS) void sa_hoist_split_kernel(const float
   };
 
   int buf = 0;
-  f32x4 pf[MT][4];
+  f32x4 pf[MTW][4];
   {
     f32x4 v;
     fetch_p(tile, pf);
@@ -312,15 +314,15 @@ __global__ __launch_bounds__(MLP_THREADS) void sa_hoist_split_kernel(const float
     const int g0 = tile * GPT;
     const bool has_next = tile + 1 < tile_end;
     StoreSplit e1{bufY1, sp_stride(C1), P1, lane};
-    run_layer_f32_t_cinit<TP, C1, MT>(w1, pf, bufX + buf * TP * XS0, wave, lane, e1);
+    run_layer_f32_t_cinit<TP, C1, MTW, NWV>(w1, pf, bufX + buf * TP * XS0, wave, lane, e1);
     f32x4 nv;
     if (has_next) { fetch_p(tile + 1, pf); fetch_x(tile + 1, nv); }   // in flight under layers 2-3
     __syncthreads();
     StoreSplit e2{bufY2, sp_stride(C2), P2, lane};
-    run_layer_split_t_pipe<TP, C1, C2>(w2, b2t, bufY1, P1, wave, lane, e2);
+    run_layer_split_t_pipe<TP, C1, C2, NWV>(w2, b2t, bufY1, P1, wave, lane, e2);
     __syncthreads();
     PoolGlobal<NS, L3::NTW> e3{out + (size_t)g0 * C3, C3, lane, {}};
-    run_layer_split_n<TP, C2, C3>(w3, b3, bufY2, P2, wave, lane, e3);
+    run_layer_split_n<TP, C2, C3, PoolGlobal<NS, L3::NTW>, NWV>(w3, b3, bufY2, P2, wave, lane, e3);
     if (has_next) put_x(buf ^ 1, nv);
     __syncthreads();
     buf ^= 1;
@@ -354,17 +356,24 @@ extern "C" int gn_sa_group_mlp_pool_split(const float *xyz, const float *new_xyz
     set_error("sa_group_mlp_pool_split: unsupported configuration mlp=[%d,%d,%d] nsample=%d", mlp[0], mlp[1], mlp[2], ns);
     return GN_ERR_INVALID_ARG;
   }
-  constexpr int TP = 128;
-  GN_REQUIRE(np % (TP / 64) == 0, "sa_group_mlp_pool_split: npoint must be even");
   const SplitWeights W{static_cast<const float *>(wpacked[0]), bias[0], wpacked[1], wpacked[2], bias[1], bias[2]};
-  const int ntiles = (int)((long)b * np / (TP / ns));
-  constexpr size_t lds = 2 * (3 * TP * sp_stride(64) + 3 * TP * sp_stride(64)) + sizeof(float) * (2 * TP * lds_stride(8));
-  auto k = sa_xyz_split_kernel<64, 64, 128, 64>;
-  int rc;
-  if ((rc = set_lds_attr(k, lds, "sa_group_mlp_pool_split"))) return rc;
-  const int tpb = split_tiles_per_block(ntiles);
-  hipLaunchKernelGGL(k, dim3((ntiles + tpb - 1) / tpb), dim3(MLP_THREADS), lds, as_stream(stream), xyz, n, new_xyz, idx, np,
-                     ntiles, tpb, radius, W, out);
+  static const int variant = []() { const char *e = getenv("GN_SA1_VARIANT"); return e ? atoi(e) : 1; }();
+  int rc = GN_OK;
+  auto launch = [&](auto k, int tp) {
+    const int ntiles = (int)((long)b * np / (tp / ns));
+    const size_t lds = 2 * (size_t)(3 * tp * sp_stride(64) + 3 * tp * sp_stride(64)) + sizeof(float) * (2 * tp * lds_stride(8));
+    if ((rc = set_lds_attr(k, lds, "sa_group_mlp_pool_split"))) return;
+    const int tpb = split_tiles_per_block(ntiles);
+    hipLaunchKernelGGL(k, dim3((ntiles + tpb - 1) / tpb), dim3(MLP_THREADS), lds, as_stream(stream), xyz, n, new_xyz, idx,
+                       np, ntiles, tpb, radius, W, out);
+  };
+  if (variant == 1) {          // one group per tile, two workgroups per CU: one's epilogues and barriers under the other's MFMAs
+    launch(sa_xyz_split_kernel<64, 64, 128, 64, 64, 2>, 64);
+  } else {
+    GN_REQUIRE(np % 2 == 0, "sa_group_mlp_pool_split: npoint must be even");
+    launch(sa_xyz_split_kernel<64, 64, 128, 64, 128, 1>, 128);
+  }
+  if (rc) return rc;
   GN_CHECK_LAUNCH("sa_group_mlp_pool_split");
   return GN_OK;
 }
@@ -388,17 +397,16 @@ extern "C" int gn_sa_hoisted_mlp_pool_split(const float *xyz, const float *pfeat
   constexpr size_t lds = 2 * (3 * TP * sp_stride(128) + 3 * TP * sp_stride(128)) + sizeof(float) * (2 * TP * lds_stride(8));
   const int tpb = split_tiles_per_block(ntiles);
   int rc;
-  if (ns == 32) {
-    auto k = sa_hoist_split_kernel<128, 128, 256, 32>;
-    if ((rc = set_lds_attr(k, lds, "sa_hoisted_mlp_pool_split"))) return rc;
-    hipLaunchKernelGGL(k, dim3((ntiles + tpb - 1) / tpb), dim3(MLP_THREADS), lds, as_stream(stream), xyz, n, pfeat, new_xyz,
-                       idx, np, ntiles, tpb, radius, W, out);
-  } else {
-    auto k = sa_hoist_split_kernel<128, 128, 256, 16>;
-    if ((rc = set_lds_attr(k, lds, "sa_hoisted_mlp_pool_split"))) return rc;
-    hipLaunchKernelGGL(k, dim3((ntiles + tpb - 1) / tpb), dim3(MLP_THREADS), lds, as_stream(stream), xyz, n, pfeat, new_xyz,
-                       idx, np, ntiles, tpb, radius, W, out);
-  }
+  auto launch = [&](auto k, int threads) {
+    if ((rc = set_lds_attr(k, lds, "sa_hoisted_mlp_pool_split"))) return;
+    hipLaunchKernelGGL(k, dim3((ntiles + tpb - 1) / tpb), dim3(threads), lds, as_stream(stream), xyz, n, pfeat, new_xyz, idx,
+                       np, ntiles, tpb, radius, W, out);
+  };
+  rc = GN_OK;
+  // (an 8-wave flavour, two waves per SIMD with half the weights each, needs ~270 registers per lane and spills)
+  if (ns == 32) launch(sa_hoist_split_kernel<128, 128, 256, 32, 4>, 256);
+  else launch(sa_hoist_split_kernel<128, 128, 256, 16, 4>, 256);
+  if (rc) return rc;
   GN_CHECK_LAUNCH("sa_hoisted_mlp_pool_split");
   return GN_OK;
 }

@@ -139,8 +139,12 @@ extern "C" int gn_graspnet_forward(const gn_weights *wt, const float *cloud, int
         GN_STAGE(kSaName[l], gn_sa_group_mlp_pool(lv_xyz, nullptr, o->sa_xyz[l], w.ball_idx[l], b, lv_n, c.npoint,
                                                   c.nsample, 0, c.radius, c.mlp, wp, bp, o->sa_features[l], st));
     } else {
-      GN_STAGE(kLin[l], gn_point_linear(lv_feat, b * lv_n, c.cin, c.mlp[0], wt->sa_pre[l].w[0], wt->sa_pre[l].b[0],
-                                        w.pfeat[l], st));
+      if (wt->use_split)
+        GN_STAGE(kLin[l], gn_point_linear_split(lv_feat, b * lv_n, c.cin, c.mlp[0], wt->sa_pre_split[l].w[0],
+                                                wt->sa_pre_split[l].b[0], w.pfeat[l], st));
+      else
+        GN_STAGE(kLin[l], gn_point_linear(lv_feat, b * lv_n, c.cin, c.mlp[0], wt->sa_pre[l].w[0], wt->sa_pre[l].b[0],
+                                          w.pfeat[l], st));
       if (wt->use_split)
         GN_STAGE(kSaName[l], gn_sa_hoisted_mlp_pool_split(lv_xyz, w.pfeat[l], o->sa_xyz[l], w.ball_idx[l], b, lv_n, c.npoint,
                                                           c.nsample, c.radius, c.mlp, wps, bps, o->sa_features[l], st));
@@ -159,15 +163,27 @@ extern "C" int gn_graspnet_forward(const gn_weights *wt, const float *cloud, int
     const float *const wp[2] = {wt->fp[0].w[0], wt->fp[0].w[1]};
     const float *const bp[2] = {wt->fp[0].b[0], wt->fp[0].b[1]};
     GN_STAGE("three_nn[fp1]", gn_three_nn(o->sa_xyz[2], o->sa_xyz[3], b, kSa[2].npoint, kSa[3].npoint, w.d2[0], w.i3[0], st));
-    GN_STAGE("fp_interp_mlp[fp1]", gn_fp_interp_mlp(o->sa_features[3], o->sa_features[2], w.d2[0], w.i3[0], b,
-                                                    kSa[2].npoint, kSa[3].npoint, 256, 256, fp_mlp, wp, bp, w.fp1, st));
+    const void *const wps[2] = {wt->fp_split[0].w[0], wt->fp_split[0].w[1]};
+    const float *const bps[2] = {wt->fp_split[0].b[0], wt->fp_split[0].b[1]};
+    if (wt->use_split)
+      GN_STAGE("fp_interp_mlp[fp1]", gn_fp_interp_mlp_split(o->sa_features[3], o->sa_features[2], w.d2[0], w.i3[0], b,
+                                                            kSa[2].npoint, kSa[3].npoint, 256, 256, fp_mlp, wps, bps, w.fp1, st));
+    else
+      GN_STAGE("fp_interp_mlp[fp1]", gn_fp_interp_mlp(o->sa_features[3], o->sa_features[2], w.d2[0], w.i3[0], b,
+                                                      kSa[2].npoint, kSa[3].npoint, 256, 256, fp_mlp, wp, bp, w.fp1, st));
   }
   {
     const float *const wp[2] = {wt->fp[1].w[0], wt->fp[1].w[1]};
     const float *const bp[2] = {wt->fp[1].b[0], wt->fp[1].b[1]};
     GN_STAGE("three_nn[fp2]", gn_three_nn(o->sa_xyz[1], o->sa_xyz[2], b, kSa[1].npoint, kSa[2].npoint, w.d2[1], w.i3[1], st));
-    GN_STAGE("fp_interp_mlp[fp2]", gn_fp_interp_mlp(w.fp1, o->sa_features[1], w.d2[1], w.i3[1], b, kSa[1].npoint,
-                                                    kSa[2].npoint, 256, 256, fp_mlp, wp, bp, o->fp2_features, st));
+    const void *const wps[2] = {wt->fp_split[1].w[0], wt->fp_split[1].w[1]};
+    const float *const bps[2] = {wt->fp_split[1].b[0], wt->fp_split[1].b[1]};
+    if (wt->use_split)
+      GN_STAGE("fp_interp_mlp[fp2]", gn_fp_interp_mlp_split(w.fp1, o->sa_features[1], w.d2[1], w.i3[1], b, kSa[1].npoint,
+                                                            kSa[2].npoint, 256, 256, fp_mlp, wps, bps, o->fp2_features, st));
+    else
+      GN_STAGE("fp_interp_mlp[fp2]", gn_fp_interp_mlp(w.fp1, o->sa_features[1], w.d2[1], w.i3[1], b, kSa[1].npoint,
+                                                      kSa[2].npoint, 256, 256, fp_mlp, wp, bp, o->fp2_features, st));
   }
   const float *seed_xyz = o->sa_xyz[1];
   const int M = kSeeds, nv = 2 + kViews;
@@ -176,7 +192,12 @@ extern "C" int gn_graspnet_forward(const gn_weights *wt, const float *cloud, int
   {
     const float *const wp[3] = {wt->approach.w[0], wt->approach.w[1], wt->approach.w[2]};
     const float *const bp[3] = {wt->approach.b[0], wt->approach.b[1], wt->approach.b[2]};
-    GN_STAGE("approach_mlp", gn_approach_mlp(o->fp2_features, b * M, 256, nv, wp, bp, o->approach, st));
+    const void *const wps[3] = {wt->approach_split.w[0], wt->approach_split.w[1], wt->approach_split.w[2]};
+    const float *const bps[3] = {wt->approach_split.b[0], wt->approach_split.b[1], wt->approach_split.b[2]};
+    if (wt->use_split)
+      GN_STAGE("approach_mlp", gn_approach_mlp_split(o->fp2_features, b * M, 256, nv, wps, bps, o->approach, st));
+    else
+      GN_STAGE("approach_mlp", gn_approach_mlp(o->fp2_features, b * M, 256, nv, wp, bp, o->approach, st));
     GN_STAGE("approach_post", gn_approach_post(o->approach, nv, b * M, kViews, wt->views, wt->view_rot, o->top_view_inds,
                                                o->top_view_score, o->top_view_xyz, o->top_view_rot, st));
   }
@@ -208,7 +229,12 @@ extern "C" int gn_graspnet_forward(const gn_weights *wt, const float *cloud, int
   {
     const float *const wp[3] = {wt->heads.w[0], wt->heads.w[1], wt->heads.w[2]};
     const float *const bp[3] = {wt->heads.b[0], wt->heads.b[1], wt->heads.b[2]};
-    GN_STAGE("heads_mlp", gn_heads_mlp(o->vp_features, b * M * kDepths, 256, 4 * kAngles, wp, bp, o->head, st));
+    const void *const wps[3] = {wt->heads_split.w[0], wt->heads_split.w[1], wt->heads_split.w[2]};
+    const float *const bps[3] = {wt->heads_split.b[0], wt->heads_split.b[1], wt->heads_split.b[2]};
+    if (wt->use_split)
+      GN_STAGE("heads_mlp", gn_heads_mlp_split(o->vp_features, b * M * kDepths, 256, 4 * kAngles, wps, bps, o->head, st));
+    else
+      GN_STAGE("heads_mlp", gn_heads_mlp(o->vp_features, b * M * kDepths, 256, 4 * kAngles, wp, bp, o->head, st));
   }
 
   // ---- pred_decode (graspnet.py:77-134)

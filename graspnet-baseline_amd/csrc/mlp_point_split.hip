@@ -1,0 +1,288 @@
+// mlp_point_split.hip -- the per-point MLP chains of mlp_point.hip (feature propagation, ApproachNet, OperationNet +
+// ToleranceNet, the hoisted per-point linear map) on the bf16 matrix cores by operand splitting (mlp_split.h).
+//
+// A tile of TP positions lives in LDS as three bf16 planes [TP][CMAX+8]; ONE buffer serves every layer: a layer's MFMAs
+// consume the whole tile (weights streamed from L2 as split fragments, 32 k per chunk, double-buffered in registers),
+// a barrier retires the input, and the epilogue writes relu(y) -- split again -- over it.  All layers run in the T
+// orientation (A = weights, B = activations): a lane ends up with 4 consecutive channels of its position per register
+// quad, i.e. one 8-byte LDS store per plane, or 4 consecutive floats of an output row.
+#include "mlp_split.h"
+
+namespace gn {
+
+struct PointSplitArgs {
+  const void *w[3];
+  const float *b[3];
+  const float *x;       // plain loader: (rows, C0) channels-last
+  const float *known;   // fp loader: (B, m, CK) features to interpolate
+  const float *skip;    //            (B, n, CS) skip features
+  const float *dist2;   //            (B, n, 3)
+  const int32_t *idx3;  //            (B, n, 3)
+  int n, m;
+  float *out;           // (rows, ldo)
+  int ldo, ncols_out;
+  int nrows;
+};
+
+__device__ __forceinline__ void store_split4(__bf16 *row, int plane, const f32x4 &v) {
+  bf16x4 hi, mid, lo;
+  split4<false>(v[0], v[1], v[2], v[3], hi, mid, lo);
+  *reinterpret_cast<bf16x4 *>(row) = hi;
+  *reinterpret_cast<bf16x4 *>(row + plane) = mid;
+  *reinterpret_cast<bf16x4 *>(row + 2 * plane) = lo;
+}
+
+// rows of a plain channels-last tensor -> planes; rows beyond nrows are zero
+template <int C0, int TP, int XS>
+__device__ __forceinline__ void load_plain_split(__bf16 *__restrict__ ys, int plane, const float *__restrict__ x, int row0,
+                                                 int nrows, int tid) {
+  constexpr int Q = C0 / 4;
+  for (int e = tid; e < TP * Q; e += MLP_THREADS) {
+    const int r = e / Q, c4 = e - r * Q;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row0 + r < nrows) v = *reinterpret_cast<const f32x4 *>(x + (size_t)(row0 + r) * C0 + c4 * 4);
+    store_split4(ys + r * XS + c4 * 4, plane, v);
+  }
+}
+
+// [ three_interpolate(known, idx, w) (CK) | skip (CS) ],  w = (1/(sqrt(d2)+1e-8)) / sum
+// (pointnet2_utils.py:138-140, pointnet2_modules.py:395-399; interpolate_gpu.cu:103-104 sum order)
+template <int CK, int CS, int TP, int XS>
+__device__ __forceinline__ void load_fp_split(__bf16 *__restrict__ ys, int plane, const PointSplitArgs &a, int row0, int tid) {
+  constexpr int QK = CK / 4, QS = CS / 4;
+  for (int e = tid; e < TP * QK; e += MLP_THREADS) {
+    const int r = e / QK, c4 = e - r * QK;
+    const int row = row0 + r;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < a.nrows) {
+      const int b = row / a.n;
+      const float *d2 = a.dist2 + (size_t)row * 3;
+      const int32_t *ix = a.idx3 + (size_t)row * 3;
+      const float r0 = 1.0f / (sqrtf(d2[0]) + 1e-8f);
+      const float r1 = 1.0f / (sqrtf(d2[1]) + 1e-8f);
+      const float r2 = 1.0f / (sqrtf(d2[2]) + 1e-8f);
+      const float norm = r0 + r1 + r2;
+      const float w0 = r0 / norm, w1 = r1 / norm, w2 = r2 / norm;
+      const float *kb = a.known + (size_t)b * a.m * CK + c4 * 4;
+      const f32x4 f0 = *reinterpret_cast<const f32x4 *>(kb + (size_t)ix[0] * CK);
+      const f32x4 f1 = *reinterpret_cast<const f32x4 *>(kb + (size_t)ix[1] * CK);
+      const f32x4 f2 = *reinterpret_cast<const f32x4 *>(kb + (size_t)ix[2] * CK);
+      v = f0 * w0 + f1 * w1 + f2 * w2;
+    }
+    store_split4(ys + r * XS + c4 * 4, plane, v);
+  }
+  for (int e = tid; e < TP * QS; e += MLP_THREADS) {
+    const int r = e / QS, c4 = e - r * QS;
+    const int row = row0 + r;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < a.nrows) v = *reinterpret_cast<const f32x4 *>(a.skip + (size_t)row * CS + c4 * 4);
+    store_split4(ys + r * XS + CK + c4 * 4, plane, v);
+  }
+}
+
+// One streamed layer, T orientation.  MFMA phase: every (M tile, n-tile) of this wave accumulates over all K with the
+// weight chunks double-buffered; then `retire()` (a workgroup barrier when the output overwrites the input) and the
+// epilogue epi(mt, nt, acc) per tile.
+template <int TP, int CINP, int COUTP, int XS, class Retire, class Epi>
+__device__ __forceinline__ void run_layer_stream_split_t(const void *__restrict__ wq, const float *__restrict__ bp,
+                                                         const __bf16 *__restrict__ xs, int xplane, int wave, int lane,
+                                                         Retire &&retire, Epi &&epi) {
+  static_assert(CINP % 32 == 0 && COUTP % 32 == 0, "K in chunks of 32");
+  constexpr int NT = COUTP / 32, WN = wn_for(COUTP), WM = 4 / WN, NTW = NT / WN, MT = TP / 32;
+  static_assert(NT % WN == 0 && MT % WM == 0, "tiles must divide over the waves");
+  constexpr int MTW = MT / WM, KB = CINP / 16, KBC = 2, NCH = KB / KBC;
+  const int wm = wave / WN, wn = wave % WN;
+  const char *wbase = static_cast<const char *>(wq);
+  asm volatile("" : "+s"(wbase), "+s"(bp));   // keep the weight loads below the barrier that precedes this layer
+  f32x16 acc[MTW][NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    float bt[16];
+    load_bias_t(bp, wn * NTW + i, lane, bt);
+#pragma unroll
+    for (int mi = 0; mi < MTW; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][i][r] = bt[r];
+  }
+  bf16x8 bbuf[2][NTW][KBC][3];
+  auto load_chunk = [&](int c, bf16x8 (&dst)[NTW][KBC][3]) {
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+      for (int kb = 0; kb < KBC; ++kb)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          dst[i][kb][p] = *reinterpret_cast<const bf16x8 *>(
+              wbase + ((((size_t)((wn * NTW + i) * KB + c * KBC + kb)) * 3 + p) * 64 + lane) * 16);
+  };
+  load_chunk(0, bbuf[0]);
+#pragma unroll 2
+  for (int c = 0; c < NCH; ++c) {
+    if (c + 1 < NCH) {
+      if (c & 1) load_chunk(c + 1, bbuf[0]); else load_chunk(c + 1, bbuf[1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < MTW; ++mi) {
+      const int mt = wm * MTW + mi;
+      const __bf16 *xr = xs + (mt * 32 + (lane & 31)) * XS + 8 * (lane >> 5) + c * KBC * 16;
+      bf16x8 a[KBC][3];
+#pragma unroll
+      for (int kb = 0; kb < KBC; ++kb)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[kb][p] = *reinterpret_cast<const bf16x8 *>(xr + p * xplane + kb * 16);
+#pragma unroll
+      for (int kb = 0; kb < KBC; ++kb)
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+          acc[mi][i] = (c & 1) ? mfma6<true>(a[kb], bbuf[1][i][kb], acc[mi][i]) : mfma6<true>(a[kb], bbuf[0][i][kb], acc[mi][i]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  retire();
+#pragma unroll
+  for (int mi = 0; mi < MTW; ++mi)
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) epi(wm * MTW + mi, wn * NTW + i, acc[mi][i]);
+}
+
+enum { PLOAD_PLAIN = 0, PLOAD_FP = 1 };
+
+// NL layers: C0 -> C1 (relu) [-> C2 (relu) [-> C3]]; the last layer goes to global (RELU_OUT), the others back to LDS.
+// CxP: padded output widths (multiples of 32 dividing over the waves); CxL: channels kept for the next layer (% 32).
+template <int LOADER, int NL, int C0, int C1P, int C1L, int C2P, int C2L, int C3P, int TP, bool RELU_OUT>
+__global__ __launch_bounds__(MLP_THREADS) void point_mlp_split_kernel(PointSplitArgs a, int ntiles) {
+  constexpr int CMAX = cmax(C0, cmax(NL > 1 ? C1L : 0, NL > 2 ? C2L : 0));
+  constexpr int XS = sp_stride(CMAX), PL = TP * XS;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __bf16 *buf = reinterpret_cast<__bf16 *>(smem_raw);    // 3 x [TP][CMAX+8]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto barrier = []() { __syncthreads(); };
+  auto none = []() {};
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row0 = tile * TP;
+    const int nrows = min(TP, a.nrows - row0);
+    if constexpr (LOADER == PLOAD_FP) load_fp_split<C0 / 2, C0 / 2, TP, XS>(buf, PL, a, row0, tid);
+    else load_plain_split<C0, TP, XS>(buf, PL, a.x, row0, a.nrows, tid);
+    __syncthreads();
+    auto to_lds = [&](int ncols) {
+      return [&, ncols](int mt, int nt, const f32x16 &acc) {
+        if (nt * 32 < ncols) {     // channels beyond the kept width are never read
+          StoreSplit e{buf, XS, PL, lane};
+          e(mt, nt, acc);
+        }
+      };
+    };
+    auto to_global = [&](int mt, int nt, const f32x16 &acc) {
+      const int row = mt * 32 + (lane & 31);
+      if (row < nrows) {
+        float *o = a.out + (size_t)(row0 + row) * a.ldo;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int ch = nt * 32 + 8 * g + 4 * (lane >> 5) + j;
+            const float v = RELU_OUT ? fmaxf(acc[4 * g + j], 0.f) : acc[4 * g + j];
+            if (ch < a.ncols_out) o[ch] = v;
+          }
+      }
+    };
+    if constexpr (NL == 1) {
+      run_layer_stream_split_t<TP, C0, C1P, XS>(a.w[0], a.b[0], buf, PL, wave, lane, none, to_global);
+    } else {
+      run_layer_stream_split_t<TP, C0, C1P, XS>(a.w[0], a.b[0], buf, PL, wave, lane, barrier, to_lds(C1L));
+      __syncthreads();
+      if constexpr (NL == 2) {
+        run_layer_stream_split_t<TP, C1L, C2P, XS>(a.w[1], a.b[1], buf, PL, wave, lane, none, to_global);
+      } else {
+        run_layer_stream_split_t<TP, C1L, C2P, XS>(a.w[1], a.b[1], buf, PL, wave, lane, barrier, to_lds(C2L));
+        __syncthreads();
+        run_layer_stream_split_t<TP, C2L, C3P, XS>(a.w[2], a.b[2], buf, PL, wave, lane, none, to_global);
+      }
+    }
+    __syncthreads();   // the next tile's loader overwrites the buffer
+  }
+}
+
+template <int LOADER, int NL, int C0, int C1P, int C1L, int C2P, int C2L, int C3P, int TP, bool RELU_OUT>
+static int launch_point_split(const PointSplitArgs &a, hipStream_t s, const char *name) {
+  constexpr int CMAX = cmax(C0, cmax(NL > 1 ? C1L : 0, NL > 2 ? C2L : 0));
+  constexpr size_t lds = 2 * (size_t)3 * TP * sp_stride(CMAX);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto k = point_mlp_split_kernel<LOADER, NL, C0, C1P, C1L, C2P, C2L, C3P, TP, RELU_OUT>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+      hipSuccess) {
+    set_error("%s: cannot reserve %zu bytes of LDS", name, lds);
+    return GN_ERR_LAUNCH;
+  }
+  const int ntiles = (a.nrows + TP - 1) / TP;
+  hipLaunchKernelGGL(k, dim3(ntiles), dim3(MLP_THREADS), lds, s, a, ntiles);
+  GN_CHECK_LAUNCH(name);
+  return GN_OK;
+}
+
+}  // namespace gn
+
+using namespace gn;
+
+extern "C" int gn_fp_interp_mlp_split(const float *known_feat, const float *skip_feat, const float *dist2, const int32_t *idx3,
+                                      int b, int n, int m, int ck, int cs, const int *mlp, const void *const *wpacked,
+                                      const float *const *bias, float *out, gn_stream_t stream) {
+  GN_REQUIRE(b >= 0 && n > 0 && m > 0, "fp_interp_mlp_split: bad sizes");
+  if (b == 0) return GN_OK;
+  GN_REQUIRE(known_feat && skip_feat && dist2 && idx3 && mlp && wpacked && bias && out, "fp_interp_mlp_split: null pointer");
+  if (!(ck == 256 && cs == 256 && mlp[0] == 256 && mlp[1] == 256)) {
+    set_error("fp_interp_mlp_split: unsupported configuration ck=%d cs=%d mlp=[%d,%d]", ck, cs, mlp[0], mlp[1]);
+    return GN_ERR_INVALID_ARG;
+  }
+  PointSplitArgs a{};
+  a.w[0] = wpacked[0]; a.b[0] = bias[0]; a.w[1] = wpacked[1]; a.b[1] = bias[1];
+  a.known = known_feat; a.skip = skip_feat; a.dist2 = dist2; a.idx3 = idx3; a.n = n; a.m = m;
+  a.out = out; a.ldo = 256; a.ncols_out = 256; a.nrows = b * n;
+  return launch_point_split<PLOAD_FP, 2, 512, 256, 256, 256, 0, 0, 32, true>(a, as_stream(stream), "fp_interp_mlp_split");
+}
+
+extern "C" int gn_approach_mlp_split(const float *x, int rows, int cin, int nout, const void *const *wpacked,
+                                     const float *const *bias, float *out, gn_stream_t stream) {
+  GN_REQUIRE(rows >= 0, "approach_mlp_split: bad sizes");
+  if (rows == 0) return GN_OK;
+  GN_REQUIRE(x && wpacked && bias && out, "approach_mlp_split: null pointer");
+  if (!(cin == 256 && nout == 302)) {
+    set_error("approach_mlp_split: unsupported configuration cin=%d nout=%d (need 256, 2+300)", cin, nout);
+    return GN_ERR_INVALID_ARG;
+  }
+  PointSplitArgs a{};
+  for (int i = 0; i < 3; ++i) { a.w[i] = wpacked[i]; a.b[i] = bias[i]; }
+  a.x = x; a.out = out; a.ldo = 302; a.ncols_out = 302; a.nrows = rows;
+  return launch_point_split<PLOAD_PLAIN, 3, 256, 256, 256, 384, 320, 384, 64, false>(a, as_stream(stream), "approach_mlp_split");
+}
+
+extern "C" int gn_heads_mlp_split(const float *x, int rows, int cin, int nout, const void *const *wpacked,
+                                  const float *const *bias, float *out, gn_stream_t stream) {
+  GN_REQUIRE(rows >= 0, "heads_mlp_split: bad sizes");
+  if (rows == 0) return GN_OK;
+  GN_REQUIRE(x && wpacked && bias && out, "heads_mlp_split: null pointer");
+  if (!(cin == 256 && nout == 48)) {
+    set_error("heads_mlp_split: unsupported configuration cin=%d nout=%d (need 256, 48)", cin, nout);
+    return GN_ERR_INVALID_ARG;
+  }
+  PointSplitArgs a{};
+  for (int i = 0; i < 3; ++i) { a.w[i] = wpacked[i]; a.b[i] = bias[i]; }
+  a.x = x; a.out = out; a.ldo = 48; a.ncols_out = 48; a.nrows = rows;
+  return launch_point_split<PLOAD_PLAIN, 3, 256, 256, 256, 256, 256, 64, 64, false>(a, as_stream(stream), "heads_mlp_split");
+}
+
+extern "C" int gn_point_linear_split(const float *x, int rows, int cin, int cout, const void *wpacked, const float *bias,
+                                     float *out, gn_stream_t stream) {
+  GN_REQUIRE(rows >= 0, "point_linear_split: bad sizes");
+  if (rows == 0) return GN_OK;
+  GN_REQUIRE(x && wpacked && bias && out, "point_linear_split: null pointer");
+  PointSplitArgs a{};
+  a.w[0] = wpacked; a.b[0] = bias; a.x = x; a.out = out; a.ldo = cout; a.ncols_out = cout; a.nrows = rows;
+  if (cin == 128 && cout == 128)
+    return launch_point_split<PLOAD_PLAIN, 1, 128, 128, 0, 0, 0, 0, 64, false>(a, as_stream(stream), "point_linear_split");
+  if (cin == 256 && cout == 128)
+    return launch_point_split<PLOAD_PLAIN, 1, 256, 128, 0, 0, 0, 0, 64, false>(a, as_stream(stream), "point_linear_split");
+  set_error("point_linear_split: unsupported configuration cin=%d cout=%d", cin, cout);
+  return GN_ERR_INVALID_ARG;
+}

@@ -28,7 +28,9 @@ class Weights(ctypes.Structure):             # gn_weights
     _fields_ = [("sa", MlpWeights * 4), ("sa_pre", MlpWeights * 4), ("fp", MlpWeights * 2), ("approach", MlpWeights),
                 ("crop", MlpWeights), ("heads", MlpWeights), ("views", _c_void_p), ("view_rot", _c_void_p),
                 ("decode_rot", _c_void_p), ("cylinder_radius", _c_float), ("hmin", _c_float), ("hmax", _c_float * 4),
-                ("use_split", _c_int), ("sa_split", MlpWeights * 4), ("crop_split", MlpWeights)]
+                ("use_split", _c_int), ("sa_split", MlpWeights * 4), ("crop_split", MlpWeights),
+                ("sa_pre_split", MlpWeights * 4), ("fp_split", MlpWeights * 2), ("approach_split", MlpWeights),
+                ("heads_split", MlpWeights)]
 
 
 class Outputs(ctypes.Structure):             # gn_outputs
@@ -92,6 +94,14 @@ SIGNATURES = {
     "gn_fp_interp_mlp": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                   ctypes.POINTER(_c_int), ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
                                   _c_void_p, _c_void_p]),
+    "gn_fp_interp_mlp_split": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                        ctypes.POINTER(_c_int), ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
+                                        _c_void_p, _c_void_p]),
+    "gn_approach_mlp_split": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, ctypes.POINTER(_c_void_p),
+                                       ctypes.POINTER(_c_void_p), _c_void_p, _c_void_p]),
+    "gn_heads_mlp_split": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
+                                    _c_void_p, _c_void_p]),
+    "gn_point_linear_split": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "gn_approach_mlp": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
                                  _c_void_p, _c_void_p]),
     "gn_heads_mlp": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),

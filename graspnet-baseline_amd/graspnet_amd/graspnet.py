@@ -145,6 +145,12 @@ class GraspNet:
         for l in (1, 2, 3):
             fill(w.sa_split[l], pk["sa%d_hoist_split" % (l + 1)])
         fill(w.crop_split, pk["crop_split"])
+        for l in (1, 2, 3):
+            fill(w.sa_pre_split[l], pk["sa%d_pre_split" % (l + 1)])
+        fill(w.fp_split[0], pk["fp1_split"])
+        fill(w.fp_split[1], pk["fp2_split"])
+        fill(w.approach_split, pk["approach_split"])
+        fill(w.heads_split, pk["heads_split"])
         w.use_split = 1 if self.math_split else 0
         return w
 
@@ -272,9 +278,15 @@ class GraspNet:
                     # layer 1's feature part once per point, then gathered as the accumulator seed
                     pre, pk = self._packed["sa%d_pre" % (li + 1)], self._packed["sa%d_hoist" % (li + 1)]
                     pfeat = torch.empty((B, lv_n, mlp[0]), dtype=f32, device=dev)
-                    self._run("point_linear[%d]" % (li + 1), lambda: lib.gn_point_linear(
-                        lv_feat.data_ptr(), B * lv_n, c, mlp[0], pre.w[0].data_ptr(), pre.b[0].data_ptr(),
-                        pfeat.data_ptr(), st))
+                    if self.math_split:
+                        pres = self._packed["sa%d_pre_split" % (li + 1)]
+                        self._run("point_linear[%d]" % (li + 1), lambda: lib.gn_point_linear_split(
+                            lv_feat.data_ptr(), B * lv_n, c, mlp[0], pres.w[0].data_ptr(), pres.b[0].data_ptr(),
+                            pfeat.data_ptr(), st))
+                    else:
+                        self._run("point_linear[%d]" % (li + 1), lambda: lib.gn_point_linear(
+                            lv_feat.data_ptr(), B * lv_n, c, mlp[0], pre.w[0].data_ptr(), pre.b[0].data_ptr(),
+                            pfeat.data_ptr(), st))
                     if self.math_split:
                         pks = self._packed["sa%d_hoist_split" % (li + 1)]
                         self._run("sa_hoisted_mlp_pool[%d]" % (li + 1), lambda: lib.gn_sa_hoisted_mlp_pool_split(
@@ -311,9 +323,10 @@ class GraspNet:
                 self._run("three_nn[%s]" % key, lambda: lib.gn_three_nn(unknown_xyz.data_ptr(), known_xyz.data_ptr(), B, n, m, d2.data_ptr(),
                                         i3.data_ptr(), st))
                 o = torch.empty((B, n, 256), dtype=f32, device=dev)
-                pk = self._packed[key]
-                self._run("fp_interp_mlp[%s]" % key, lambda: lib.gn_fp_interp_mlp(known.data_ptr(), skip.data_ptr(), d2.data_ptr(), i3.data_ptr(), B, n, m,
-                                             256, 256, _ci(256, 256), pk.wptr, pk.bptr, o.data_ptr(), st))
+                pk = self._packed[key + "_split" if self.math_split else key]
+                fn = lib.gn_fp_interp_mlp_split if self.math_split else lib.gn_fp_interp_mlp
+                self._run("fp_interp_mlp[%s]" % key, lambda: fn(known.data_ptr(), skip.data_ptr(), d2.data_ptr(), i3.data_ptr(), B, n,
+                                                                  m, 256, 256, _ci(256, 256), pk.wptr, pk.bptr, o.data_ptr(), st))
                 return o
 
             g1 = fp(end_points["sa3_xyz"], end_points["sa4_xyz"], feats[2], feats[3], "fp1")
@@ -327,8 +340,9 @@ class GraspNet:
             # ---- ApproachNet (modules.py:41-77)
             nv = 2 + self.num_view
             feat302 = torch.empty((B, M, nv), dtype=f32, device=dev)
-            pk = self._packed["approach"]
-            self._run("approach_mlp", lambda: lib.gn_approach_mlp(seed_feat.data_ptr(), B * M, 256, nv, pk.wptr, pk.bptr, feat302.data_ptr(), st))
+            pk = self._packed["approach_split" if self.math_split else "approach"]
+            fn_a = lib.gn_approach_mlp_split if self.math_split else lib.gn_approach_mlp
+            self._run("approach_mlp", lambda: fn_a(seed_feat.data_ptr(), B * M, 256, nv, pk.wptr, pk.bptr, feat302.data_ptr(), st))
             views, view_rot, decode_rot = self._tables
             top_inds = torch.empty((B, M), dtype=torch.int64, device=dev)
             top_score = torch.empty((B, M), dtype=f32, device=dev)
@@ -383,8 +397,9 @@ class GraspNet:
             # ---- OperationNet + ToleranceNet (modules.py:169-191, 214-232)
             A = self.num_angle
             head = torch.empty((B, M, D, 4 * A), dtype=f32, device=dev)
-            pk = self._packed["heads"]
-            self._run("heads_mlp", lambda: lib.gn_heads_mlp(vp.data_ptr(), B * M * D, 256, 4 * A, pk.wptr, pk.bptr, head.data_ptr(), st))
+            pk = self._packed["heads_split" if self.math_split else "heads"]
+            fn_h = lib.gn_heads_mlp_split if self.math_split else lib.gn_heads_mlp
+            self._run("heads_mlp", lambda: fn_h(vp.data_ptr(), B * M * D, 256, 4 * A, pk.wptr, pk.bptr, head.data_ptr(), st))
             hv = head.permute(0, 3, 1, 2)                                            # (B,48,M,D) view
             end_points["grasp_score_pred"] = hv[:, 0:A]
             end_points["grasp_angle_cls_pred"] = hv[:, A:2 * A]

@@ -105,6 +105,7 @@ def prepare(sd, device, num_view=300, num_angle=12):
         if c > 0:
             # layer 1 split for the hoisted kernel: per-point part W1f (+ bias) and per-neighbour K=8 block W1x
             out["sa%d_pre" % (li + 1)] = PackedMlp([pack_fragments(w0[:, :c], b0)], device)
+            out["sa%d_pre_split" % (li + 1)] = PackedMlp([pack_split(w0[:, :c], b0)], device)
             out["sa%d_hoist" % (li + 1)] = PackedMlp(
                 [pack_fragments(w0[:, c:], torch.zeros_like(b0), cinp=8)] + [pack_fragments(w, b) for w, b in layers[1:]],
                 device)
@@ -113,6 +114,7 @@ def prepare(sd, device, num_view=300, num_angle=12):
     for i in (1, 2):
         layers = _shared_mlp_layers(sd, "%s.fp%d.mlp" % (bb, i), 2)
         out["fp%d" % i] = PackedMlp([pack_fragments(w, b) for w, b in layers], device)
+        out["fp%d_split" % i] = PackedMlp([pack_split(w, b) for w, b in layers], device)
     vp = "view_estimator.vpmodule"
     nv = 2 + num_view
     l1 = fold_bn(sd[vp + ".conv1.weight"], sd[vp + ".conv1.bias"], sd, vp + ".bn1")
@@ -122,6 +124,8 @@ def prepare(sd, device, num_view=300, num_angle=12):
     out["approach"] = PackedMlp([pack_fragments(*l1), pack_fragments(*l2, coutp=nvp),
                                  pack_fragments(*l3, cinp=pad_to(nv, 32), coutp=nvp)], device)   # K padded to 320: chunks of 80
     crop_layers = _shared_mlp_layers(sd, "grasp_generator.crop.mlps", 3)
+    out["approach_split"] = PackedMlp([pack_split(*l1), pack_split(*l2, coutp=nvp),
+                                       pack_split(*l3, cinp=pad_to(nv, 32), coutp=nvp)], device)
     out["crop"] = PackedMlp([pack_fragments(w, b, cinp=8 if i == 0 else None) for i, (w, b) in enumerate(crop_layers)], device)
     # layers 2-3 as split-bf16 fragments for the matrix-core path (layer 1, K = 3, stays fp32)
     out["crop_split"] = PackedMlp([pack_fragments(*crop_layers[0], cinp=8), pack_split(*crop_layers[1]),
@@ -142,4 +146,5 @@ def prepare(sd, device, num_view=300, num_angle=12):
     w3 = torch.zeros(no + nt_, 2 * h); w3[:no, :h] = o3[0]; w3[no:, h:] = t3[0]
     b3 = torch.cat([o3[1], t3[1]], 0)
     out["heads"] = PackedMlp([pack_fragments(w1, b1), pack_fragments(w2, b2), pack_fragments(w3, b3)], device)
+    out["heads_split"] = PackedMlp([pack_split(w1, b1), pack_split(w2, b2), pack_split(w3, b3)], device)
     return out

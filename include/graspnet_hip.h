@@ -234,6 +234,19 @@ int gn_fp_interp_mlp(const float *known_feat, const float *skip_feat, const floa
                      const float *const *wpacked, const float *const *bias, float *out,
                      gn_stream_t stream);
 
+/* The per-point chains below on the bf16 matrix cores (csrc/mlp_point_split.hip): same arguments and results as
+ * gn_fp_interp_mlp / gn_approach_mlp / gn_heads_mlp / gn_point_linear, every layer's weights as split fragments
+ * (graspnet_amd/weights.py: pack_split, K padded to a multiple of 32). */
+int gn_fp_interp_mlp_split(const float *known_feat, const float *skip_feat, const float *dist2, const int32_t *idx3, int b,
+                           int n, int m, int ck, int cs, const int *mlp, const void *const *wpacked,
+                           const float *const *bias, float *out, gn_stream_t stream);
+int gn_approach_mlp_split(const float *x, int rows, int cin, int nout, const void *const *wpacked, const float *const *bias,
+                          float *out, gn_stream_t stream);
+int gn_heads_mlp_split(const float *x, int rows, int cin, int nout, const void *const *wpacked, const float *const *bias,
+                       float *out, gn_stream_t stream);
+int gn_point_linear_split(const float *x, int rows, int cin, int cout, const void *wpacked, const float *bias, float *out,
+                          gn_stream_t stream);
+
 /* ApproachNet conv1/bn1/relu, conv2/bn2/relu, conv3 (models/modules.py:55-57):
  * x (rows,256) -> out (rows, 2+num_view) = [objectness | view scores]. */
 int gn_approach_mlp(const float *x, int rows, int cin, int nout, const float *const *wpacked,
@@ -286,6 +299,8 @@ typedef struct gn_weights {
   int use_split;
   gn_mlp_weights sa_split[4];
   gn_mlp_weights crop_split;
+  gn_mlp_weights sa_pre_split[4];  /* [l].w[0]/b[0], l >= 1 */
+  gn_mlp_weights fp_split[2], approach_split, heads_split;   /* all layers split */
 } gn_weights;
 
 typedef struct gn_outputs {          /* device buffers owned by the caller; all required unless noted */

@@ -199,6 +199,14 @@ def main():
                     "measured": "HIP events on the launch stream; avg_launch_ms from a single-stream pass of the same "
                                 "steps right after the timed region (inside it, kernels of up to %d batches share the "
                                 "chip and a launch's bracket includes that contention)" % len(streams)}
+            # HBM traffic of this kernel cannot be counted from inside the process: it comes from the committed PMC passes
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r1d_pmc_traffic.json")))[rk]
+                if net.math_split and B == 8:
+                    roof["traffic"] = pmc["traffic_bytes"]
+                    roof["traffic_source"] = "profiles/r1d_pmc_traffic.json: " + pmc["how"]
+            except (OSError, KeyError, ValueError):
+                pass
             uc = last_ep.get("_gn", {}).get("ucount")
             if uc is not None:
                 # the de-duplicated path executes fewer MACs than the reference algorithm: report the

@@ -18,9 +18,10 @@ import os
 import sys
 import time
 
-# ROCm maps HIP streams onto this many hardware queues (default 4).  The bench overlaps up to 8
+# ROCm maps HIP streams onto this many hardware queues (default 4).  The bench overlaps up to 12
 # batches (FPS is a serial chain on 8 CUs per batch); with too few queues two batches share a queue
-# and serialise (measured, 200 steps: 4 queues/3 streams 2050, 8/6 3900, 16/8 4150 scenes/s).
+# and serialise (measured with the fp32 kernels, 200 steps: 4 queues/3 streams 2050, 8/6 3900, 16/8 4150
+# scenes/s; with the split kernels, 150 steps at 16 queues: 8 streams 6030, 10: 6110, 12: 6320, 14: 6280, 16: 5710).
 # Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
@@ -103,7 +104,7 @@ def main():
     ap.add_argument("--global-batch", type=int, default=0,
                     help="strong scaling: a fixed global batch cut into contiguous per-rank shards "
                          "(default 0 = weak scaling, --batch scenes on every rank)")
-    ap.add_argument("--streams", type=int, default=8,
+    ap.add_argument("--streams", type=int, default=12,
                     help="HIP streams the steps are issued round-robin on (FPS is a serial chain on 8 CUs per "
                          "batch; other batches' kernels fill the rest of the chip meanwhile)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -127,6 +127,12 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_unique_split_kernel(const fl
     else
       run_layer_split_t<TP, C1, C2>(w2, b2t, bufY1, P1, wave, lane, e2, mtc);
     GN_PROBE(3);
+    // the next chunk's input tile and gates go into the other halves of their double buffers here, so that this
+    // barrier also publishes them and no third barrier is needed: layer 1 of the next chunk only writes Y1 (nobody
+    // reads it any more) and layer 2 of the next chunk starts behind its own barrier, i.e. after every wave has left
+    // this chunk's layer 3
+    if (has_next && tid < TP) put(buf ^ 1, tid, nv, ng);
+    GN_PROBE(7);
     __syncthreads();
     GN_PROBE(4);
     if constexpr (PIPE & 2)
@@ -140,10 +146,6 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_unique_split_kernel(const fl
     }
     GN_PROBE(6);
     if (!has_next) break;
-    if (tid < TP) put(buf ^ 1, tid, nv, ng);
-    GN_PROBE(7);
-    __syncthreads();   // next input tile visible; Y1/Y2 free
-    GN_PROBE(8);
     GN_PROBE_COUNT(9, 1);
     GN_PROBE_COUNT(10, mtc);
     buf ^= 1;
@@ -222,11 +224,10 @@ __global__ __launch_bounds__(MLP_THREADS, MINW) void sa_xyz_split_kernel(const f
     __syncthreads();
     StoreSplit e2{bufY2, sp_stride(C2), P2, lane};
     run_layer_split_t_pipe<TP, C1, C2>(w2, b2t, bufY1, P1, wave, lane, e2);
+    if (has_next) put_x(buf ^ 1, nv);   // published by the barrier below: no third barrier per tile (see the crop kernel)
     __syncthreads();
     PoolGlobal<NS, L3::NTW> e3{out + (size_t)g0 * C3, C3, lane, {}};
     run_layer_split_n<TP, C2, C3>(w3, b3, bufY2, P2, wave, lane, e3);
-    if (has_next) put_x(buf ^ 1, nv);
-    __syncthreads();
     buf ^= 1;
   }
 }
@@ -320,11 +321,10 @@ __global__ __launch_bounds__(NWV * 64) void sa_hoist_split_kernel(const float *_
     __syncthreads();
     StoreSplit e2{bufY2, sp_stride(C2), P2, lane};
     run_layer_split_t_pipe<TP, C1, C2, NWV>(w2, b2t, bufY1, P1, wave, lane, e2);
+    if (has_next) put_x(buf ^ 1, nv);   // published by the barrier below
     __syncthreads();
     PoolGlobal<NS, L3::NTW> e3{out + (size_t)g0 * C3, C3, lane, {}};
     run_layer_split_n<TP, C2, C3, PoolGlobal<NS, L3::NTW>, NWV>(w3, b3, bufY2, P2, wave, lane, e3);
-    if (has_next) put_x(buf ^ 1, nv);
-    __syncthreads();
     buf ^= 1;
   }
 }

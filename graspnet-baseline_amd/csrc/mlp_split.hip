@@ -341,8 +341,9 @@ static int split_tiles_per_block(int ntiles) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
     if (cus <= 0) cus = 256;
   }
-  int tpb = ntiles / (cus * 4);
-  return tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
+  static const int div_env = []() { const char *e = getenv("GN_SA_WGS_PER_CU"); return e ? atoi(e) : 0; }();
+  int tpb = ntiles / (cus * (div_env > 0 ? div_env : 4));
+  return tpb < 1 ? 1 : (tpb > 64 ? 64 : tpb);
 }
 
 extern "C" int gn_sa_group_mlp_pool_split(const float *xyz, const float *new_xyz, const int32_t *idx, int b, int n, int np,

@@ -25,11 +25,11 @@ struct PointSplitArgs {
 };
 
 __device__ __forceinline__ void store_split4(__bf16 *row, int plane, const f32x4 &v) {
-  bf16x4 hi, mid, lo;
+  u32x2 hi, mid, lo;
   split4<false>(v[0], v[1], v[2], v[3], hi, mid, lo);
-  *reinterpret_cast<bf16x4 *>(row) = hi;
-  *reinterpret_cast<bf16x4 *>(row + plane) = mid;
-  *reinterpret_cast<bf16x4 *>(row + 2 * plane) = lo;
+  *reinterpret_cast<u32x2 *>(row) = hi;
+  *reinterpret_cast<u32x2 *>(row + plane) = mid;
+  *reinterpret_cast<u32x2 *>(row + 2 * plane) = lo;
 }
 
 // rows of a plain channels-last tensor -> planes; rows beyond nrows are zero

@@ -65,19 +65,40 @@ __device__ __forceinline__ f32x16 mfma6(const bf16x8 (&x)[3], const bf16x8 (&w)[
   return acc;
 }
 
-// exact three-way split of four fp32 values (ReLU first if asked)
+// exact three-way split of four fp32 values (ReLU first if asked) into three packed bf16x4 (two dwords each).
+// Written pair-wise on purpose: one v_cvt_pk_bf16_f32 per pair and level, the bf16 pair widened back with a shift and a
+// mask, the residual by one v_pk_add_f32 -- 13 VALU per pair instead of the ~27 hipcc emits for the scalar form (it
+// converts every value twice and canonicalises before each fmaxf).  No NaNs can occur here.
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+
+// ReLU as v_med3_f32(x, 0, +inf): fmaxf() makes hipcc canonicalise its operand first (a second v_max per value),
+// and inline asm must not touch MFMA results (the hazard recognizer does not see inside it: the two-workgroup SA1
+// kernel keeps its accumulators in VGPRs and read them too early that way).
+__device__ __forceinline__ float relu_raw(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
+__device__ __forceinline__ unsigned cvt_pk_bf16(f32x2 v) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ f32x2 widen_bf16x2(unsigned u) {
+  return f32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+}
+__device__ __forceinline__ void split2(f32x2 x, unsigned &hi, unsigned &mid, unsigned &lo) {
+  hi = cvt_pk_bf16(x);
+  const f32x2 r = x - widen_bf16x2(hi);
+  mid = cvt_pk_bf16(r);
+  const f32x2 r2 = r - widen_bf16x2(mid);
+  lo = cvt_pk_bf16(r2);
+}
 template <bool RELU>
-__device__ __forceinline__ void split4(float v0, float v1, float v2, float v3, bf16x4 &hi, bf16x4 &mid, bf16x4 &lo) {
-  float v[4] = {v0, v1, v2, v3};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float x = RELU ? fmaxf(v[j], 0.f) : v[j];
-    hi[j] = (__bf16)x;
-    const float r = x - (float)hi[j];
-    mid[j] = (__bf16)r;
-    const float r2 = r - (float)mid[j];
-    lo[j] = (__bf16)r2;
-  }
+__device__ __forceinline__ void split4(float v0, float v1, float v2, float v3, u32x2 &hi, u32x2 &mid, u32x2 &lo) {
+  if (RELU) { v0 = relu_raw(v0); v1 = relu_raw(v1); v2 = relu_raw(v2); v3 = relu_raw(v3); }
+  unsigned h0, m0, l0, h1, m1, l1;
+  split2(f32x2{v0, v1}, h0, m0, l0);
+  split2(f32x2{v2, v3}, h1, m1, l1);
+  hi = u32x2{h0, h1};
+  mid = u32x2{m0, m1};
+  lo = u32x2{l0, l1};
 }
 
 // T-orientation epilogue: ReLU, split, store the tile into the next layer's three planes
@@ -90,11 +111,11 @@ struct StoreSplit {
     __bf16 *row = ys + (mt * 32 + (lane & 31)) * stride + nt * 32 + 4 * (lane >> 5);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      bf16x4 hi, mid, lo;
+      u32x2 hi, mid, lo;
       split4<true>(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], hi, mid, lo);
-      *reinterpret_cast<bf16x4 *>(row + 8 * g) = hi;
-      *reinterpret_cast<bf16x4 *>(row + 8 * g + plane) = mid;
-      *reinterpret_cast<bf16x4 *>(row + 8 * g + 2 * plane) = lo;
+      *reinterpret_cast<u32x2 *>(row + 8 * g) = hi;
+      *reinterpret_cast<u32x2 *>(row + 8 * g + plane) = mid;
+      *reinterpret_cast<u32x2 *>(row + 8 * g + 2 * plane) = lo;
     }
   }
 };
@@ -226,11 +247,11 @@ __device__ __forceinline__ void run_layer_split_t_pipe(const LayerWS<CINP, COUTP
   };
   auto store_quarter = [&](const f32x16 &src, int mt, int g) {
     __bf16 *row = epi.ys + (mt * 32 + (lane & 31)) * epi.stride + wn * 32 + 4 * (lane >> 5) + 8 * g;
-    bf16x4 hi, mid, lo;
+    u32x2 hi, mid, lo;
     split4<true>(src[4 * g], src[4 * g + 1], src[4 * g + 2], src[4 * g + 3], hi, mid, lo);
-    *reinterpret_cast<bf16x4 *>(row) = hi;
-    *reinterpret_cast<bf16x4 *>(row + epi.plane) = mid;
-    *reinterpret_cast<bf16x4 *>(row + 2 * epi.plane) = lo;
+    *reinterpret_cast<u32x2 *>(row) = hi;
+    *reinterpret_cast<u32x2 *>(row + epi.plane) = mid;
+    *reinterpret_cast<u32x2 *>(row + 2 * epi.plane) = lo;
   };
   mma(acc[0], wm, [](int) {});
 #pragma unroll

@@ -64,6 +64,48 @@ void run(const char *name, const void *wp, float *out, unsigned long long *cyc, 
   printf("%-26s mtc=%d blocks=%d: %.3f ms  %.1f cycles per MFMA (ideal 32), wall %.2f ns\n", name, mtc, blocks, ms, avg / mfma, ms * 1e6 / mfma);
 }
 
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bench_t(const void *wp, float *out, unsigned long long *cyc, int reps, int mtc) {
+  constexpr int TP = 96, CIN = 64, COUT = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __bf16 *x = reinterpret_cast<__bf16 *>(smem_raw);
+  constexpr int PL = TP * sp_stride(CIN), PO = TP * sp_stride(COUT);
+  __bf16 *y = x + 3 * PL;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 3 * PL; i += 256) x[i] = (__bf16)((float)((i * 7) % 13) * 0.01f);
+  LayerWS<CIN, COUT> w;
+  w.load(wp, wave, lane);
+  __syncthreads();
+  float bt[16];
+  for (int r = 0; r < 16; ++r) bt[r] = 0.01f * r;
+  StoreSplit e{y, sp_stride(COUT), PO, lane};
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int r = 0; r < reps; ++r) {
+    if (MODE == 0) run_layer_split_t<TP, CIN, COUT>(w, bt, x, PL, wave, lane, e, mtc);
+    if constexpr (MODE == 1) run_layer_split_t_pipe<TP, CIN, COUT>(w, bt, x, PL, wave, lane, e, mtc);
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  out[blockIdx.x * 256 + tid] = (float)y[tid];
+  if (lane == 0) cyc[blockIdx.x * 4 + wave] = t1 - t0;
+}
+
+template <int MODE>
+void run_t(const char *name, const void *wp, float *out, unsigned long long *cyc, int mtc) {
+  const int reps = 200;
+  const size_t lds = 2 * 3 * 96 * (sp_stride(64) + sp_stride(128));
+  auto k = bench_t<MODE>;
+  hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  k<<<1, 256, lds>>>(wp, out, cyc, 2, mtc);
+  if (hipGetLastError() != hipSuccess) { printf("launch failed\n"); return; }
+  k<<<1, 256, lds>>>(wp, out, cyc, reps, mtc);
+  hipDeviceSynchronize();
+  unsigned long long h[4];
+  hipMemcpy(h, cyc, 32, hipMemcpyDeviceToHost);
+  const double mfma = (double)mtc * 4 * 6 * reps;
+  printf("%-26s mtc=%d: %.1f cycles per MFMA (ideal 32), %.0f cycles per M tile\n", name, mtc, (double)h[0] / mfma, (double)h[0] / (mtc * reps));
+}
+
 int main() {
   void *wp; float *out; unsigned long long *cyc;
   hipMalloc(&wp, 256 * 128 * 6); hipMalloc(&out, 4096 * 256 * 4); hipMalloc(&cyc, 4096 * 4 * 8);
@@ -74,5 +116,6 @@ int main() {
       run<1>("split N + masked pool", wp, out, cyc, blocks, mtc);
       run<2>("split N + pool, pipelined", wp, out, cyc, blocks, mtc);
     }
+  for (int mtc : {3, 2}) { run_t<0>("split T 64->128 + store", wp, out, cyc, mtc); run_t<1>("split T, pipelined", wp, out, cyc, mtc); }
   return 0;
 }

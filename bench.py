@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--streams", type=int, default=12,
                     help="HIP streams the steps are issued round-robin on (FPS is a serial chain on 8 CUs per "
                          "batch; other batches' kernels fill the rest of the chip meanwhile)")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse the N>1 code "
+                         "path with several ranks sharing one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scenes", type=int, default=16)
     args = ap.parse_args()
@@ -117,8 +120,12 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())

@@ -1,0 +1,50 @@
+"""GPU: bench.py's output contract (one JSON line, required keys) for N=1, and a rehearsal of the N>1 code path
+(rank sharding, barrier + max-over-ranks timing, the all-gather of the grasp lists) with two ranks sharing the one GPU of
+the test box over gloo -- the real N>1 runs use RCCL and are the driver's."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _last_json(text):
+    lines = [l for l in text.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "bench.py must print exactly one JSON line, got %d" % len(lines)
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_contract():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "12", "--cpu-scenes", "1"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["unit"] == "scenes/s" and d["value"] > 250.0            # the per-GPU target of BASELINE.json
+    assert abs(d["value"] - 8 * 12 / (d["ms_per_step"] * 12e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["avg_launch_ms"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_bench_two_ranks_share_the_gpu_over_gloo():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "6", "--warmup", "4", "--backend", "gloo"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["cpu_baseline"] is None and d["config"]["parallelism"] == "scene shards x2"
+    assert abs(d["value"] - 2 * 8 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
+    assert 16 * 300 < d["grasps_last_step"] < 16 * 1024          # every rank holds all 16 scenes' grasp lists

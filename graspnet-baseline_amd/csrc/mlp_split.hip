@@ -44,17 +44,29 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_unique_split_kernel(const fl
   float *bufG = bufX + 2 * TP * XS0;                               // 2 x [TP][4] pooling gates
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-  LayerW<CIN0, C1> w1;
   LayerWS<C1, C2> w2;
   LayerWS<C2, C3> w3;
-  using L1 = LayerW<CIN0, C1>;
   using L2 = LayerWS<C1, C2>;
   using L3 = LayerWS<C2, C3>;
-  w1.load(W.w1, W.b1, wave, lane);
   w2.load(W.w2, wave, lane);
   w3.load(W.w3, wave, lane);
-  float b1t[16], b2t[16], b3[L3::NTW];
-  load_bias_t(W.b1, wave % L1::WN, lane, b1t);
+  // Layer 1 (K = 3) on the vector ALUs, one (row, 8-channel) item per thread and M tile: 256 items per tile = exactly
+  // one per thread, whatever the tile count (as 32x32 MFMA tiles it is 2 per M tile on 4 waves: 6 tiles on 4 waves in
+  // the common 3-tile chunk, and the other two waves waited at the barrier).  The thread's 8 channels' weights come
+  // out of the fp32 fragment image: W1[c][k] = Wp[((c/32)*64 + c%32)*4 + k].
+  static_assert(C1 == 64, "8 threads x 8 channels cover a row");
+  float w1v[8][3], b1v[8];
+  {
+    const int c0 = (tid & 7) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j;
+      const float *wp = W.w1 + (size_t)(((c >> 5) * 64 + (c & 31)) * 4);
+      w1v[j][0] = wp[0]; w1v[j][1] = wp[1]; w1v[j][2] = wp[2];
+      b1v[j] = W.b1[c];
+    }
+  }
+  float b2t[16], b3[L3::NTW];
   load_bias_t(W.b2, wave % L2::WN, lane, b2t);
 #pragma unroll
   for (int i = 0; i < L3::NTW; ++i) b3[i] = W.b3[((wave % L3::WN) * L3::NTW + i) * 32 + (lane & 31)];
@@ -116,8 +128,25 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_unique_split_kernel(const fl
     GN_PROBE(0);
 
     pool.sgate = bufG + buf * TP * 4;
-    StoreSplit e1{bufY1, sp_stride(C1), P1, lane};
-    run_layer_f32_t<TP, C1>(w1, b1t, bufX + buf * TP * XS0, wave, lane, e1, mtc);
+    {
+      const float *xin = bufX + buf * TP * XS0;
+      for (int mt = 0; mt < mtc; ++mt) {
+        const int row = mt * 32 + (tid >> 3);
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(xin + row * XS0);
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          y[j] = __builtin_fmaf(xv[2], w1v[j][2], __builtin_fmaf(xv[1], w1v[j][1], __builtin_fmaf(xv[0], w1v[j][0], b1v[j])));
+        u32x2 h0, m0, l0, h1, m1, l1;
+        split4<true>(y[0], y[1], y[2], y[3], h0, m0, l0);
+        split4<true>(y[4], y[5], y[6], y[7], h1, m1, l1);
+        using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+        __bf16 *dst = bufY1 + row * sp_stride(C1) + (tid & 7) * 8;
+        *reinterpret_cast<u32x4 *>(dst) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+        *reinterpret_cast<u32x4 *>(dst + P1) = u32x4{m0[0], m0[1], m1[0], m1[1]};
+        *reinterpret_cast<u32x4 *>(dst + 2 * P1) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+      }
+    }
     GN_PROBE(1);
     __syncthreads();
     GN_PROBE(2);

@@ -380,16 +380,17 @@ def test_library_sequenced_forward_equals_stage_calls(net, state_dict, clouds, N
     from graspnet_amd import GraspNet, _lib as L
     staged = GraspNet().load_state_dict(state_dict)
     staged.native_forward = False
+    native = GraspNet().load_state_dict(state_dict)
+    native.native_forward = True
     x = clouds.cuda()[:, :N].contiguous()
-    a = net({"point_clouds": x})
+    a = native({"point_clouds": x})
     b = staged({"point_clouds": x})
-    assert net.native_forward and "workspace" not in b["_gn"]
     keys = [k for k in b if k not in ("_gn", "input_features", "point_clouds")]
     assert set(keys) <= set(a)
     for k in keys:
         assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype, k
         assert torch.equal(a[k], b[k]), k
-    ga, ca = net.decode_padded(a)
+    ga, ca = native.decode_padded(a)
     gb, cb = staged.decode_padded(b)
     assert torch.equal(ga, gb) and torch.equal(ca, cb)
     for k in ("ucount", "vp"):
@@ -414,17 +415,17 @@ def test_library_sequenced_forward_equals_stage_calls(net, state_dict, clouds, N
     grasps = torch.empty((B, 1024, 17), device="cuda"); counts = torch.empty((B,), dtype=torch.int32, device="cuda")
     o.grasps, o.counts = grasps.data_ptr(), counts.data_ptr()
     ws = torch.empty((lib.gn_graspnet_workspace_bytes(B, N),), dtype=torch.uint8, device="cuda")
-    rc = lib.gn_graspnet_forward(ctypes.byref(net._cweights), x.data_ptr(), B, N, ws.data_ptr(), ctypes.byref(o),
+    rc = lib.gn_graspnet_forward(ctypes.byref(native._cweights), x.data_ptr(), B, N, ws.data_ptr(), ctypes.byref(o),
                                  L.STAGE_HOOK(), None, torch.cuda.current_stream().cuda_stream)
     assert rc == 0, lib.gn_last_error()
     torch.cuda.synchronize()
     assert torch.equal(grasps, ga) and torch.equal(counts, ca)
     # argument checking: too small a cloud / missing output are refused with a message, not a fault
-    assert lib.gn_graspnet_forward(ctypes.byref(net._cweights), x.data_ptr(), B, 100, ws.data_ptr(), ctypes.byref(o),
+    assert lib.gn_graspnet_forward(ctypes.byref(native._cweights), x.data_ptr(), B, 100, ws.data_ptr(), ctypes.byref(o),
                                    L.STAGE_HOOK(), None, None) != 0
     assert b"at least" in lib.gn_last_error()
     o.head = None
-    assert lib.gn_graspnet_forward(ctypes.byref(net._cweights), x.data_ptr(), B, N, ws.data_ptr(), ctypes.byref(o),
+    assert lib.gn_graspnet_forward(ctypes.byref(native._cweights), x.data_ptr(), B, N, ws.data_ptr(), ctypes.byref(o),
                                    L.STAGE_HOOK(), None, None) != 0
 
 

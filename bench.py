@@ -146,6 +146,13 @@ def main():
     clouds = S.make_batch(1000 + lo, B, N, "uniform").to(dev)
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+    # torch's caching allocator keeps one pool per stream: reserve each stream's pool up front (setup, like creating the
+    # streams) so that a stream's first step does not spend its time in hipMalloc when --warmup is smaller than --streams
+    per_step = 6 * B * (N * 12 + 4 * 1024 * 1024)        # ~2x the outputs + workspace of one step (0.2 GB at B=8)
+    for st in streams:
+        with torch.cuda.stream(st):
+            blk = torch.empty((per_step,), dtype=torch.uint8, device=dev)
+            del blk
     torch.cuda.synchronize()
 
     last = {}

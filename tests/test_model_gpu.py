@@ -256,6 +256,7 @@ def test_sa_hoisted_equals_plain(net, state_dict, clouds):
     plain.sa_hoist = False
     plain.math_split = False
     hoisted = GraspNet().load_state_dict(state_dict)
+    hoisted.sa_hoist = True
     hoisted.math_split = False             # the fp32 MFMA kernels: same k order with and without hoisting
     a = hoisted({"point_clouds": clouds.cuda()})
     b = plain({"point_clouds": clouds.cuda()})
@@ -382,6 +383,8 @@ def test_library_sequenced_forward_equals_stage_calls(net, state_dict, clouds, N
     staged.native_forward = False
     native = GraspNet().load_state_dict(state_dict)
     native.native_forward = True
+    for n_ in (staged, native):          # the library sequences the default fast path; pin it whatever the GN_* env says
+        n_.crop_unique = n_.sa_hoist = n_.query_grid = True
     x = clouds.cuda()[:, :N].contiguous()
     a = native({"point_clouds": x})
     b = staged({"point_clouds": x})

@@ -100,6 +100,23 @@ extern "C" int gn_graspnet_forward(const gn_weights *wt, const float *cloud, int
                  o->top_view_rot && o->vp_features && o->head,
              "graspnet_forward: null output");
   GN_REQUIRE(!o->grasps == !o->counts, "graspnet_forward: grasps and counts go together");
+  {   // every layer pointer of the weight set that will be used
+    auto full = [](const gn_mlp_weights &m, int nl) {
+      for (int i = 0; i < nl; ++i)
+        if (!m.w[i] || !m.b[i]) return false;
+      return true;
+    };
+    bool ok = wt->views && wt->view_rot && wt->decode_rot;
+    if (wt->use_split) {
+      ok = ok && full(wt->crop_split, 3) && full(wt->approach_split, 3) && full(wt->heads_split, 3) &&
+           full(wt->fp_split[0], 2) && full(wt->fp_split[1], 2);
+      for (int l = 0; l < 4; ++l) ok = ok && full(wt->sa_split[l], 3) && (l == 0 || full(wt->sa_pre_split[l], 1));
+    } else {
+      ok = ok && full(wt->crop, 3) && full(wt->approach, 3) && full(wt->heads, 3) && full(wt->fp[0], 2) && full(wt->fp[1], 2);
+      for (int l = 0; l < 4; ++l) ok = ok && full(wt->sa[l], 3) && (l == 0 || full(wt->sa_pre[l], 1));
+    }
+    GN_REQUIRE(ok, "graspnet_forward: a weight or bias pointer of the %s set is null", wt->use_split ? "split" : "fp32");
+  }
   const Workspace w = carve(workspace, b, n);
   int32_t *uidx = o->crop_uidx ? o->crop_uidx : w.uidx;
   int32_t *ucount = o->crop_ucount ? o->crop_ucount : w.ucount;

@@ -216,12 +216,14 @@ __global__ __launch_bounds__(MLP_THREADS, MINW) void sa_xyz_split_kernel(const f
   const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * tpb);
   int tile = blockIdx.x * tpb;
   if (tile >= tile_end) return;
-  auto fetch_x = [&](int tl, f32x4 &v) {
+  // the neighbour index of the tile after next is loaded while the next tile's coordinates are gathered (see the
+  // hoisted kernel below)
+  auto fetch_i = [&](int tl) -> int { return tid < TP ? idx[(size_t)tl * GPT * NS + tid] : 0; };
+  auto fetch_x = [&](int tl, int src, f32x4 &v) {
     const int g0 = tl * GPT;
     const int b = g0 / np;
     v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid < TP) {
-      const int src = idx[(size_t)g0 * NS + tid];
       const float *c = new_xyz + ((size_t)g0 + tid / NS) * 3;
       const float *px = xyz + (size_t)b * n * 3;
       v[0] = (px[src * 3 + 0] - c[0]) / radius;   // pointnet2_utils.py:346-348
@@ -237,9 +239,12 @@ __global__ __launch_bounds__(MLP_THREADS, MINW) void sa_xyz_split_kernel(const f
     }
   };
   int buf = 0;
+  int sxn;
   {
     f32x4 v;
-    fetch_x(tile, v);
+    sxn = fetch_i(tile);
+    fetch_x(tile, sxn, v);
+    if (tile + 1 < tile_end) sxn = fetch_i(tile + 1);
     put_x(0, v);
   }
   __syncthreads();
@@ -247,7 +252,10 @@ __global__ __launch_bounds__(MLP_THREADS, MINW) void sa_xyz_split_kernel(const f
     const int g0 = tile * GPT;
     const bool has_next = tile + 1 < tile_end;
     f32x4 nv;
-    if (has_next) fetch_x(tile + 1, nv);          // in flight under the three layers
+    if (has_next) {                               // in flight under the three layers
+      fetch_x(tile + 1, sxn, nv);
+      if (tile + 2 < tile_end) sxn = fetch_i(tile + 2);
+    }
     StoreSplit e1{bufY1, sp_stride(C1), P1, lane};
     run_layer_f32_t<TP, C1>(w1, b1t, bufX + buf * TP * XS0, wave, lane, e1);
     __syncthreads();
@@ -297,25 +305,30 @@ __global__ __launch_bounds__(NWV * 64) void sa_hoist_split_kernel(const float *_
   int tile = blockIdx.x * tpb;
   if (tile >= tile_end) return;
 
-  // this lane's accumulator-initial rows of tile tl: position mt*32 + (lane&31), channels wave*32 + 8g + 4(lane>>5) ..+3
-  auto fetch_p = [&](int tl, f32x4 (&pf)[MTW][4]) {
-    const int g0 = tl * GPT;
-    const int b = g0 / np;
-    const int32_t *ix = idx + (size_t)g0 * NS;
+  // The neighbour indices are fetched one tile ahead of the rows they address (two tiles ahead of their use): a row
+  // gather issued right behind its index load would stall the wave for a full L2 round trip in front of layer 2.
+  // this lane's accumulator-initial rows of tile tl: position mt*32 + (lane&31), channels wn*32 + 8g + 4(lane>>5) ..+3
+  auto fetch_i = [&](int tl, int (&ix)[MTW], int &sx) {
+    const int32_t *ixb = idx + (size_t)tl * GPT * NS;
+#pragma unroll
+    for (int mi = 0; mi < MTW; ++mi) ix[mi] = ixb[(wave / L1::WN + mi * L1::WM) * 32 + (lane & 31)];
+    sx = tid < TP ? ixb[tid] : 0;
+  };
+  auto fetch_p = [&](int tl, const int (&ix)[MTW], f32x4 (&pf)[MTW][4]) {
+    const int b = (tl * GPT) / np;
     const float *pb = pfeat + (size_t)b * n * C1 + (wave % L1::WN) * 32 + 4 * (lane >> 5);
 #pragma unroll
     for (int mi = 0; mi < MTW; ++mi) {
-      const float *row = pb + (size_t)ix[(wave / L1::WN + mi * L1::WM) * 32 + (lane & 31)] * C1;
+      const float *row = pb + (size_t)ix[mi] * C1;
 #pragma unroll
       for (int g = 0; g < 4; ++g) pf[mi][g] = *reinterpret_cast<const f32x4 *>(row + 8 * g);
     }
   };
-  auto fetch_x = [&](int tl, f32x4 &v) {
+  auto fetch_x = [&](int tl, int src, f32x4 &v) {
     const int g0 = tl * GPT;
     const int b = g0 / np;
     v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid < TP) {
-      const int src = idx[(size_t)g0 * NS + tid];
       const float *c = new_xyz + ((size_t)g0 + tid / NS) * 3;
       const float *px = xyz + (size_t)b * n * 3;
       v[0] = (px[src * 3 + 0] - c[0]) / radius;   // pointnet2_utils.py:346-348
@@ -333,29 +346,46 @@ __global__ __launch_bounds__(NWV * 64) void sa_hoist_split_kernel(const float *_
 
   int buf = 0;
   f32x4 pf[MTW][4];
+  int ixn[MTW], sxn;
   {
     f32x4 v;
-    fetch_p(tile, pf);
-    fetch_x(tile, v);
+    fetch_i(tile, ixn, sxn);
+    fetch_p(tile, ixn, pf);
+    fetch_x(tile, sxn, v);
+    if (tile + 1 < tile_end) fetch_i(tile + 1, ixn, sxn);
     put_x(0, v);
   }
   __syncthreads();
+  GN_PROBE_INIT();
   for (; tile < tile_end; ++tile) {
     const int g0 = tile * GPT;
     const bool has_next = tile + 1 < tile_end;
+    GN_PROBE(0);
     StoreSplit e1{bufY1, sp_stride(C1), P1, lane};
     run_layer_f32_t_cinit<TP, C1, MTW, NWV>(w1, pf, bufX + buf * TP * XS0, wave, lane, e1);
     f32x4 nv;
-    if (has_next) { fetch_p(tile + 1, pf); fetch_x(tile + 1, nv); }   // in flight under layers 2-3
+    if (has_next) {     // rows of the next tile (their indices arrived during the previous tile), then the indices after
+      fetch_p(tile + 1, ixn, pf);
+      fetch_x(tile + 1, sxn, nv);
+      if (tile + 2 < tile_end) fetch_i(tile + 2, ixn, sxn);
+    }
+    GN_PROBE(1);
     __syncthreads();
+    GN_PROBE(2);
     StoreSplit e2{bufY2, sp_stride(C2), P2, lane};
     run_layer_split_t_pipe<TP, C1, C2, NWV>(w2, b2t, bufY1, P1, wave, lane, e2);
     if (has_next) put_x(buf ^ 1, nv);   // published by the barrier below
+    GN_PROBE(3);
     __syncthreads();
+    GN_PROBE(4);
     PoolGlobal<NS, L3::NTW> e3{out + (size_t)g0 * C3, C3, lane, {}};
     run_layer_split_n<TP, C2, C3, PoolGlobal<NS, L3::NTW>, NWV>(w3, b3, bufY2, P2, wave, lane, e3);
+    GN_PROBE(5);
+    GN_PROBE_COUNT(9, 1);
+    GN_PROBE_COUNT(10, MT);
     buf ^= 1;
   }
+  GN_PROBE_FLUSH();
 }
 
 }  // namespace gn

@@ -18,6 +18,8 @@ for it in range(3):
     net({"point_clouds": x})
     torch.cuda.synchronize()
     (lib.gn_phase_probe_read_split if net.math_split else lib.gn_phase_probe_read)(buf, 1)
+# note: with the split path the table sums the CloudCrop kernel AND the hoisted SA2-4 kernels (same translation unit);
+# GN_PROBE_ONLY=sa / crop restricts the forward to one of them by running the other on the fp32 kernels
 names = ["fetch-issue", "L1", "bar1", "L2", "bar2", "L3+pool", "finish", "put", "bar3", "chunks", "mtiles"]
 tot_all = 0
 for w in range(8):

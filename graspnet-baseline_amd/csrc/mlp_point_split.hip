@@ -32,16 +32,29 @@ __device__ __forceinline__ void store_split4(__bf16 *row, int plane, const f32x4
   *reinterpret_cast<u32x2 *>(row + 2 * plane) = lo;
 }
 
-// rows of a plain channels-last tensor -> planes; rows beyond nrows are zero
+// rows of a plain channels-last tensor -> planes; rows beyond nrows are zero.  The loads of a batch of up to 16 float4 per
+// thread are all issued before the first one is split (one memory round trip per batch instead of one per float4).
 template <int C0, int TP, int XS>
 __device__ __forceinline__ void load_plain_split(__bf16 *__restrict__ ys, int plane, const float *__restrict__ x, int row0,
                                                  int nrows, int tid) {
-  constexpr int Q = C0 / 4;
-  for (int e = tid; e < TP * Q; e += MLP_THREADS) {
-    const int r = e / Q, c4 = e - r * Q;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row0 + r < nrows) v = *reinterpret_cast<const f32x4 *>(x + (size_t)(row0 + r) * C0 + c4 * 4);
-    store_split4(ys + r * XS + c4 * 4, plane, v);
+  constexpr int Q = C0 / 4, PER = TP * Q / MLP_THREADS, BATCH = PER % 16 == 0 ? 16 : (PER % 8 == 0 ? 8 : (PER % 4 == 0 ? 4 : 1));
+  static_assert(TP * Q % MLP_THREADS == 0, "tile must divide over the threads");
+#pragma unroll 1
+  for (int e0 = 0; e0 < PER; e0 += BATCH) {
+    f32x4 v[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int e = tid + (e0 + u) * MLP_THREADS;
+      const int r = e / Q, c4 = e - r * Q;
+      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row0 + r < nrows) v[u] = *reinterpret_cast<const f32x4 *>(x + (size_t)(row0 + r) * C0 + c4 * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int e = tid + (e0 + u) * MLP_THREADS;
+      const int r = e / Q, c4 = e - r * Q;
+      store_split4(ys + r * XS + c4 * 4, plane, v[u]);
+    }
   }
 }
 
@@ -49,77 +62,135 @@ __device__ __forceinline__ void load_plain_split(__bf16 *__restrict__ ys, int pl
 // (pointnet2_utils.py:138-140, pointnet2_modules.py:395-399; interpolate_gpu.cu:103-104 sum order)
 template <int CK, int CS, int TP, int XS>
 __device__ __forceinline__ void load_fp_split(__bf16 *__restrict__ ys, int plane, const PointSplitArgs &a, int row0, int tid) {
-  constexpr int QK = CK / 4, QS = CS / 4;
-  for (int e = tid; e < TP * QK; e += MLP_THREADS) {
-    const int r = e / QK, c4 = e - r * QK;
-    const int row = row0 + r;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row < a.nrows) {
-      const int b = row / a.n;
-      const float *d2 = a.dist2 + (size_t)row * 3;
-      const int32_t *ix = a.idx3 + (size_t)row * 3;
-      const float r0 = 1.0f / (sqrtf(d2[0]) + 1e-8f);
-      const float r1 = 1.0f / (sqrtf(d2[1]) + 1e-8f);
-      const float r2 = 1.0f / (sqrtf(d2[2]) + 1e-8f);
-      const float norm = r0 + r1 + r2;
-      const float w0 = r0 / norm, w1 = r1 / norm, w2 = r2 / norm;
-      const float *kb = a.known + (size_t)b * a.m * CK + c4 * 4;
-      const f32x4 f0 = *reinterpret_cast<const f32x4 *>(kb + (size_t)ix[0] * CK);
-      const f32x4 f1 = *reinterpret_cast<const f32x4 *>(kb + (size_t)ix[1] * CK);
-      const f32x4 f2 = *reinterpret_cast<const f32x4 *>(kb + (size_t)ix[2] * CK);
-      v = f0 * w0 + f1 * w1 + f2 * w2;
+  constexpr int QK = CK / 4, QS = CS / 4, PERK = TP * QK / MLP_THREADS, PERS = TP * QS / MLP_THREADS, BATCH = 4;
+  static_assert(TP * QK % MLP_THREADS == 0 && TP * QS % MLP_THREADS == 0 && PERK % BATCH == 0 && PERS % BATCH == 0,
+                "tile must divide over the threads in batches of 4");
+#pragma unroll 1
+  for (int e0 = 0; e0 < PERK; e0 += BATCH) {     // all gathers of a batch in flight before the first blend
+    f32x4 f0[BATCH], f1[BATCH], f2[BATCH];
+    float w0[BATCH], w1[BATCH], w2[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int e = tid + (e0 + u) * MLP_THREADS;
+      const int r = e / QK, c4 = e - r * QK;
+      const int row = row0 + r;
+      f0[u] = f1[u] = f2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      w0[u] = w1[u] = w2[u] = 0.f;
+      if (row < a.nrows) {
+        const int b = row / a.n;
+        const float *d2 = a.dist2 + (size_t)row * 3;
+        const int32_t *ix = a.idx3 + (size_t)row * 3;
+        const float r0 = 1.0f / (sqrtf(d2[0]) + 1e-8f);
+        const float r1 = 1.0f / (sqrtf(d2[1]) + 1e-8f);
+        const float r2 = 1.0f / (sqrtf(d2[2]) + 1e-8f);
+        const float norm = r0 + r1 + r2;
+        w0[u] = r0 / norm; w1[u] = r1 / norm; w2[u] = r2 / norm;
+        const float *kb = a.known + (size_t)b * a.m * CK + c4 * 4;
+        f0[u] = *reinterpret_cast<const f32x4 *>(kb + (size_t)ix[0] * CK);
+        f1[u] = *reinterpret_cast<const f32x4 *>(kb + (size_t)ix[1] * CK);
+        f2[u] = *reinterpret_cast<const f32x4 *>(kb + (size_t)ix[2] * CK);
+      }
     }
-    store_split4(ys + r * XS + c4 * 4, plane, v);
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int e = tid + (e0 + u) * MLP_THREADS;
+      const int r = e / QK, c4 = e - r * QK;
+      const f32x4 v = f0[u] * w0[u] + f1[u] * w1[u] + f2[u] * w2[u];
+      store_split4(ys + r * XS + c4 * 4, plane, v);
+    }
   }
-  for (int e = tid; e < TP * QS; e += MLP_THREADS) {
-    const int r = e / QS, c4 = e - r * QS;
-    const int row = row0 + r;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row < a.nrows) v = *reinterpret_cast<const f32x4 *>(a.skip + (size_t)row * CS + c4 * 4);
-    store_split4(ys + r * XS + CK + c4 * 4, plane, v);
+#pragma unroll 1
+  for (int e0 = 0; e0 < PERS; e0 += BATCH) {
+    f32x4 v[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int e = tid + (e0 + u) * MLP_THREADS;
+      const int r = e / QS, c4 = e - r * QS;
+      const int row = row0 + r;
+      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row < a.nrows) v[u] = *reinterpret_cast<const f32x4 *>(a.skip + (size_t)row * CS + c4 * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int e = tid + (e0 + u) * MLP_THREADS;
+      const int r = e / QS, c4 = e - r * QS;
+      store_split4(ys + r * XS + CK + c4 * 4, plane, v[u]);
+    }
   }
 }
 
 // One streamed layer, T orientation.  MFMA phase: every (M tile, n-tile) of this wave accumulates over all K with the
 // weight chunks double-buffered; then `retire()` (a workgroup barrier when the output overwrites the input) and the
 // epilogue epi(mt, nt, acc) per tile.
+template <int COUTP>
+struct StreamBias {      // this wave's accumulator-initial values (T orientation: 16 channel rows per n-tile), loaded once
+  static constexpr int NTW = (COUTP / 32) / wn_for(COUTP);
+  float v[NTW][16];
+  __device__ __forceinline__ void load(const float *__restrict__ bp, int wave, int lane) {
+    const int wn = wave % wn_for(COUTP);
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) load_bias_t(bp, wn * NTW + i, lane, v[i]);
+  }
+};
+
+// shape of a streamed layer for this kernel family
+template <int TP, int CINP, int COUTP>
+struct StreamCfg {
+  static_assert(CINP % 32 == 0 && COUTP % 32 == 0, "K in chunks of at least 32");
+  static constexpr int NT = COUTP / 32, WN = wn_for(COUTP), WM = 4 / WN, NTW = NT / WN, MT = TP / 32;
+  static_assert(NT % WN == 0 && MT % WM == 0, "tiles must divide over the waves");
+  // k-blocks per weight chunk: at least ~48 MFMAs behind every chunk load (an L2 round trip), so small layers take
+  // longer chunks
+  static constexpr int MTW = MT / WM, KB = CINP / 16;
+  static constexpr int KBC0 = (MTW * NTW >= 4) ? 2 : (MTW * NTW >= 2 ? 4 : 8);
+  static constexpr int KBC = (KB % KBC0 == 0) ? KBC0 : 2;
+  static constexpr int NCH = KB / KBC;
+  static_assert(KB % KBC == 0, "K must be a multiple of the chunk");
+};
+
+// one chunk of this wave's split weight fragments in registers
+template <int TP, int CINP, int COUTP>
+struct StreamChunk {
+  using C = StreamCfg<TP, CINP, COUTP>;
+  bf16x8 v[C::NTW][C::KBC][3];
+  __device__ __forceinline__ void load(const void *__restrict__ wq, int c, int wave, int lane) {
+    const int wn = wave % C::WN;
+    const char *wbase = static_cast<const char *>(wq);
+#pragma unroll
+    for (int i = 0; i < C::NTW; ++i)
+#pragma unroll
+      for (int kb = 0; kb < C::KBC; ++kb)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          v[i][kb][p] = *reinterpret_cast<const bf16x8 *>(
+              wbase + ((((size_t)((wn * C::NTW + i) * C::KB + c * C::KBC + kb)) * 3 + p) * 64 + lane) * 16);
+  }
+};
+
+// (Requesting the NEXT layer's chunk 0 while this layer finishes -- each layer otherwise starts with an L2 round trip
+// for its first chunk, ~2.5 k cycles -- keeps three layers' chunk buffers live across the tile loop and spills
+// 250-850 bytes per lane as written; left for a restructured kernel.)
 template <int TP, int CINP, int COUTP, int XS, class Retire, class Epi>
-__device__ __forceinline__ void run_layer_stream_split_t(const void *__restrict__ wq, const float *__restrict__ bp,
+__device__ __forceinline__ void run_layer_stream_split_t(const void *__restrict__ wq, const StreamBias<COUTP> &bias,
                                                          const __bf16 *__restrict__ xs, int xplane, int wave, int lane,
                                                          Retire &&retire, Epi &&epi) {
-  static_assert(CINP % 32 == 0 && COUTP % 32 == 0, "K in chunks of 32");
-  constexpr int NT = COUTP / 32, WN = wn_for(COUTP), WM = 4 / WN, NTW = NT / WN, MT = TP / 32;
-  static_assert(NT % WN == 0 && MT % WM == 0, "tiles must divide over the waves");
-  constexpr int MTW = MT / WM, KB = CINP / 16, KBC = 2, NCH = KB / KBC;
+  using C = StreamCfg<TP, CINP, COUTP>;
+  constexpr int WN = C::WN, NTW = C::NTW, MTW = C::MTW, KBC = C::KBC, NCH = C::NCH;
   const int wm = wave / WN, wn = wave % WN;
-  const char *wbase = static_cast<const char *>(wq);
-  asm volatile("" : "+s"(wbase), "+s"(bp));   // keep the weight loads below the barrier that precedes this layer
+  asm volatile("" : "+s"(wq));   // keep this layer's own chunk loads below the barrier that precedes it
   f32x16 acc[MTW][NTW];
 #pragma unroll
-  for (int i = 0; i < NTW; ++i) {
-    float bt[16];
-    load_bias_t(bp, wn * NTW + i, lane, bt);
+  for (int i = 0; i < NTW; ++i)
 #pragma unroll
     for (int mi = 0; mi < MTW; ++mi)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][i][r] = bt[r];
-  }
-  bf16x8 bbuf[2][NTW][KBC][3];
-  auto load_chunk = [&](int c, bf16x8 (&dst)[NTW][KBC][3]) {
-#pragma unroll
-    for (int i = 0; i < NTW; ++i)
-#pragma unroll
-      for (int kb = 0; kb < KBC; ++kb)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          dst[i][kb][p] = *reinterpret_cast<const bf16x8 *>(
-              wbase + ((((size_t)((wn * NTW + i) * KB + c * KBC + kb)) * 3 + p) * 64 + lane) * 16);
-  };
-  load_chunk(0, bbuf[0]);
+      for (int r = 0; r < 16; ++r) acc[mi][i][r] = bias.v[i][r];
+  StreamChunk<TP, CINP, COUTP> first, other;
+  first.load(wq, 0, wave, lane);
 #pragma unroll 2
   for (int c = 0; c < NCH; ++c) {
     if (c + 1 < NCH) {
-      if (c & 1) load_chunk(c + 1, bbuf[0]); else load_chunk(c + 1, bbuf[1]);
+      if (c & 1) first.load(wq, c + 1, wave, lane); else other.load(wq, c + 1, wave, lane);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -135,7 +206,7 @@ __device__ __forceinline__ void run_layer_stream_split_t(const void *__restrict_
       for (int kb = 0; kb < KBC; ++kb)
 #pragma unroll
         for (int i = 0; i < NTW; ++i)
-          acc[mi][i] = (c & 1) ? mfma6<true>(a[kb], bbuf[1][i][kb], acc[mi][i]) : mfma6<true>(a[kb], bbuf[0][i][kb], acc[mi][i]);
+          acc[mi][i] = (c & 1) ? mfma6<true>(a[kb], other.v[i][kb], acc[mi][i]) : mfma6<true>(a[kb], first.v[i][kb], acc[mi][i]);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -159,12 +230,25 @@ __global__ __launch_bounds__(MLP_THREADS) void point_mlp_split_kernel(PointSplit
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   auto barrier = []() { __syncthreads(); };
   auto none = []() {};
+  // biases in registers for the whole kernel: fetched per layer they put an L2 round trip in front of each layer's
+  // first MFMA (the accumulators start from them)
+  StreamBias<C1P> bias1;
+  StreamBias<(NL > 1 ? C2P : 128)> bias2;
+  StreamBias<(NL > 2 ? C3P : 128)> bias3;
+  bias1.load(a.b[0], wave, lane);
+  if constexpr (NL > 1) bias2.load(a.b[1], wave, lane);
+  if constexpr (NL > 2) bias3.load(a.b[2], wave, lane);
+
+  GN_PROBE_INIT();
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    GN_PROBE(7);
     const int row0 = tile * TP;
     const int nrows = min(TP, a.nrows - row0);
     if constexpr (LOADER == PLOAD_FP) load_fp_split<C0 / 2, C0 / 2, TP, XS>(buf, PL, a, row0, tid);
     else load_plain_split<C0, TP, XS>(buf, PL, a.x, row0, a.nrows, tid);
+    GN_PROBE(0);
     __syncthreads();
+    GN_PROBE(1);
     auto to_lds = [&](int ncols) {
       return [&, ncols](int mt, int nt, const f32x16 &acc) {
         if (nt * 32 < ncols) {     // channels beyond the kept width are never read
@@ -188,20 +272,27 @@ __global__ __launch_bounds__(MLP_THREADS) void point_mlp_split_kernel(PointSplit
       }
     };
     if constexpr (NL == 1) {
-      run_layer_stream_split_t<TP, C0, C1P, XS>(a.w[0], a.b[0], buf, PL, wave, lane, none, to_global);
+      run_layer_stream_split_t<TP, C0, C1P, XS>(a.w[0], bias1, buf, PL, wave, lane, none, to_global);
     } else {
-      run_layer_stream_split_t<TP, C0, C1P, XS>(a.w[0], a.b[0], buf, PL, wave, lane, barrier, to_lds(C1L));
+      run_layer_stream_split_t<TP, C0, C1P, XS>(a.w[0], bias1, buf, PL, wave, lane, barrier, to_lds(C1L));
+      GN_PROBE(2);
       __syncthreads();
+      GN_PROBE(3);
       if constexpr (NL == 2) {
-        run_layer_stream_split_t<TP, C1L, C2P, XS>(a.w[1], a.b[1], buf, PL, wave, lane, none, to_global);
+        run_layer_stream_split_t<TP, C1L, C2P, XS>(a.w[1], bias2, buf, PL, wave, lane, none, to_global);
       } else {
-        run_layer_stream_split_t<TP, C1L, C2P, XS>(a.w[1], a.b[1], buf, PL, wave, lane, barrier, to_lds(C2L));
+        run_layer_stream_split_t<TP, C1L, C2P, XS>(a.w[1], bias2, buf, PL, wave, lane, barrier, to_lds(C2L));
+        GN_PROBE(4);
         __syncthreads();
-        run_layer_stream_split_t<TP, C2L, C3P, XS>(a.w[2], a.b[2], buf, PL, wave, lane, none, to_global);
+        GN_PROBE(5);
+        run_layer_stream_split_t<TP, C2L, C3P, XS>(a.w[2], bias3, buf, PL, wave, lane, none, to_global);
+        GN_PROBE(6);
       }
     }
     __syncthreads();   // the next tile's loader overwrites the buffer
+    GN_PROBE_COUNT(9, 1);
   }
+  GN_PROBE_FLUSH();
 }
 
 template <int LOADER, int NL, int C0, int C1P, int C1L, int C2P, int C2L, int C3P, int TP, bool RELU_OUT>
@@ -286,3 +377,5 @@ extern "C" int gn_point_linear_split(const float *x, int rows, int cin, int cout
   set_error("point_linear_split: unsupported configuration cin=%d cout=%d", cin, cout);
   return GN_ERR_INVALID_ARG;
 }
+
+GN_PROBE_READER(gn_phase_probe_read_point)

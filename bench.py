@@ -216,10 +216,10 @@ def main():
                                 "chip and a launch's bracket includes that contention)" % len(streams)}
             # HBM traffic of this kernel cannot be counted from inside the process: it comes from the committed PMC passes
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r1f_pmc_traffic.json")))[rk]
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r1g_pmc_traffic.json")))[rk]
                 if net.math_split and B == 8:
                     roof["traffic"] = pmc["traffic_bytes"]
-                    roof["traffic_source"] = "profiles/r1f_pmc_traffic.json: " + pmc["how"]
+                    roof["traffic_source"] = "profiles/r1g_pmc_traffic.json: " + pmc["how"]
             except (OSError, KeyError, ValueError):
                 pass
             uc = last_ep.get("_gn", {}).get("ucount")

@@ -73,58 +73,86 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_unique_split_kernel(const fl
   PoolMasked<ND, L3::NTW> pool{bufG, lane, {}};
   pool.reset();
 
-  const int s_end = min(nseeds, (int)(blockIdx.x + 1) * spb);
-  int sf = blockIdx.x * spb;
-  if (sf >= s_end) return;
-  int nu = ucount[sf], row0 = 0;
-
-  auto fetch = [&](int csf, int crow0, int cnu, int p, f32x4 &v, f32x4 &g) {
-    v = f32x4{0.f, 0.f, 0.f, 0.f};
-    g = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    if (crow0 + p < cnu) {
-      const int e = uidx[(size_t)csf * CAP + crow0 + p];
-      const int src = e & 0x0fffffff;
+  // ---- chunk walk.  The row fetch is a chain of dependent global loads (entry count -> uidx entry -> coordinates);
+  // issued back to back it stalls the fetching waves for an L2 round trip per link at the top of every chunk.  So the
+  // workgroup's entry counts go to LDS once, a chunk's uidx entries are requested two chunks ahead and its coordinates
+  // (plus the seed's centre / rotation, whose address needs no load) one chunk ahead.
+  constexpr int MAXSPB = 16;
+  __shared__ int s_cnt[MAXSPB];
+  const int s0 = blockIdx.x * spb;
+  const int s_end = min(nseeds, s0 + spb);
+  if (s0 >= s_end) return;
+  if (tid < MAXSPB) s_cnt[tid] = (s0 + tid < s_end) ? ucount[s0 + tid] : 0;
+  __syncthreads();
+  struct Cur { int sf, row0, nu; };
+  auto advance = [&](const Cur &c) {
+    Cur r = c;
+    if (c.row0 + TP >= c.nu) {
+      r.sf = c.sf + 1;
+      r.row0 = 0;
+      r.nu = r.sf < s_end ? s_cnt[r.sf - s0] : 0;
+    } else {
+      r.row0 = c.row0 + TP;
+    }
+    return r;
+  };
+  auto load_e = [&](const Cur &c) -> int {      // -1 = padding row
+    return (tid < TP && c.sf < s_end && c.row0 + tid < c.nu) ? uidx[(size_t)c.sf * CAP + c.row0 + tid] : -1;
+  };
+  // raw row of chunk c: coordinates of its point, centre and rotation of its seed (no arithmetic yet)
+  struct Raw { float px, py, pz, c0, c1, c2, r[9]; };
+  auto load_raw = [&](const Cur &c, int e, Raw &w) {
+    if (e != -1) {
+      const float *pp = xyz + ((size_t)(c.sf / m) * n + (e & 0x0fffffff)) * 3;
+      const float *cc = seed + (size_t)c.sf * 3;
+      const float *rr = rot + (size_t)c.sf * 9;
+      w.px = pp[0]; w.py = pp[1]; w.pz = pp[2];
+      w.c0 = cc[0]; w.c1 = cc[1]; w.c2 = cc[2];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) w.r[i] = rr[i];
+    }
+  };
+  auto put = [&](int buf, int e, const Raw &w) {
+    if (tid >= TP) return;
+    f32x4 v{0.f, 0.f, 0.f, 0.f}, g{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (e != -1) {
       const unsigned mk = (unsigned)e >> 28;
-      const float *c = seed + (size_t)csf * 3;
-      const float *r = rot + (size_t)csf * 9;
-      const float *px = xyz + (size_t)(csf / m) * n * 3;
-      const float x = px[src * 3 + 0] - c[0];
-      const float y = px[src * 3 + 1] - c[1];
-      const float z = px[src * 3 + 2] - c[2];
-      v[0] = x * r[0] + y * r[3] + z * r[6];   // (p-c)^T R, pointnet2_utils.py:528-530
-      v[1] = x * r[1] + y * r[4] + z * r[7];
-      v[2] = x * r[2] + y * r[5] + z * r[8];
+      const float x = w.px - w.c0, y = w.py - w.c1, z = w.pz - w.c2;
+      v[0] = x * w.r[0] + y * w.r[3] + z * w.r[6];   // (p-c)^T R, pointnet2_utils.py:528-530
+      v[1] = x * w.r[1] + y * w.r[4] + z * w.r[7];
+      v[2] = x * w.r[2] + y * w.r[5] + z * w.r[8];
 #pragma unroll
       for (int d = 0; d < ND; ++d) g[d] = ((mk >> d) & 1u) ? 0.f : -INFINITY;
     }
-  };
-  auto put = [&](int buf, int p, const f32x4 &v, const f32x4 &g) {
-    float *x = bufX + buf * TP * XS0 + p * XS0;
-    *reinterpret_cast<f32x4 *>(x) = v;
-    *reinterpret_cast<f32x4 *>(x + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-    *reinterpret_cast<f32x4 *>(bufG + buf * TP * 4 + p * 4) = g;
+    float *xo = bufX + buf * TP * XS0 + tid * XS0;
+    *reinterpret_cast<f32x4 *>(xo) = v;
+    *reinterpret_cast<f32x4 *>(xo + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4 *>(bufG + buf * TP * 4 + tid * 4) = g;
   };
 
-  int buf = 0;
+  Cur cur{s0, 0, s_cnt[0]};
+  Cur n1 = advance(cur), n2 = advance(n1);
+  int buf = 0, ent1, ent2 = -1;
   {
-    f32x4 v, g;
-    if (tid < TP) { fetch(sf, row0, nu, tid, v, g); put(0, tid, v, g); }
+    const int e0 = load_e(cur);
+    ent1 = load_e(n1);
+    Raw w0{};
+    load_raw(cur, e0, w0);
+    put(0, e0, w0);
   }
   __syncthreads();
   GN_PROBE_INIT();
   while (true) {
-    const int rows = min(TP, nu - row0);
+    const int sf = cur.sf;
+    const int rows = min(TP, cur.nu - cur.row0);
     const int mtc = (rows + 31) >> 5;
-    const bool seed_done = row0 + TP >= nu;
-    int nsf = sf, nrow0 = row0 + TP, nnu = nu;
-    if (seed_done) {
-      nsf = sf + 1;
-      nrow0 = 0;
-      nnu = nsf < s_end ? ucount[nsf] : 0;
+    const bool seed_done = cur.row0 + TP >= cur.nu;
+    const bool has_next = n1.sf < s_end;
+    Raw w1{};
+    if (has_next) {
+      load_raw(n1, ent1, w1);         // its entries were requested a whole chunk ago
+      ent2 = load_e(n2);              // entries of the chunk after next
     }
-    const bool has_next = nsf < s_end;
-    f32x4 nv, ng;
-    if (has_next && tid < TP) fetch(nsf, nrow0, nnu, tid, nv, ng);   // in flight during the layers below
     GN_PROBE(0);
 
     pool.sgate = bufG + buf * TP * 4;
@@ -160,7 +188,7 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_unique_split_kernel(const fl
     // barrier also publishes them and no third barrier is needed: layer 1 of the next chunk only writes Y1 (nobody
     // reads it any more) and layer 2 of the next chunk starts behind its own barrier, i.e. after every wave has left
     // this chunk's layer 3
-    if (has_next && tid < TP) put(buf ^ 1, tid, nv, ng);
+    if (has_next) put(buf ^ 1, ent1, w1);
     GN_PROBE(7);
     __syncthreads();
     GN_PROBE(4);
@@ -178,7 +206,8 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_unique_split_kernel(const fl
     GN_PROBE_COUNT(9, 1);
     GN_PROBE_COUNT(10, mtc);
     buf ^= 1;
-    sf = nsf; row0 = nrow0; nu = nnu;
+    cur = n1; n1 = n2; n2 = advance(n2);
+    ent1 = ent2;
   }
   GN_PROBE_FLUSH();
 }

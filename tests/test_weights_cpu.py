@@ -1,0 +1,74 @@
+"""CPU: host-side weight preparation (BN folding, fragment packing, exact bf16 splitting) against the index formulas the
+kernels read with (csrc/mlp_core.h, csrc/mlp_split.h)."""
+import torch
+
+from graspnet_amd import weights as W
+
+
+def test_fold_bn_matches_eval_batchnorm():
+    torch.manual_seed(0)
+    conv = torch.nn.Conv1d(16, 24, 1, bias=True)
+    bn = torch.nn.BatchNorm1d(24).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_()
+    sd = {"bn.weight": bn.weight.detach(), "bn.bias": bn.bias.detach(), "bn.running_mean": bn.running_mean,
+          "bn.running_var": bn.running_var}
+    w, b = W.fold_bn(conv.weight.detach(), conv.bias.detach(), sd, "bn")
+    x = torch.randn(3, 16, 50)
+    want = bn(conv(x))
+    got = torch.einsum("oc,bcn->bon", w, x) + b[None, :, None]
+    assert torch.allclose(got, want, atol=1e-5, rtol=1e-5)
+
+
+def test_fp32_fragment_layout():
+    torch.manual_seed(1)
+    w, b = torch.randn(70, 19), torch.randn(70)
+    frag, bp = W.pack_fragments(w, b)
+    coutp, cinp = W.coutp_for(70), W.pad_to(19, 8)
+    assert frag.shape == (coutp // 32, cinp // 8, 64, 4) and bp.shape == (coutp,)
+    wp = torch.zeros(coutp, cinp); wp[:70, :19] = w
+    for nt, kb, lane, s in ((0, 0, 0, 0), (1, 2, 37, 3), (2, 1, 63, 1), (coutp // 32 - 1, cinp // 8 - 1, 33, 2)):
+        assert frag[nt, kb, lane, s] == wp[nt * 32 + (lane & 31), kb * 8 + 4 * (lane >> 5) + s]
+    assert torch.equal(bp[:70], b) and float(bp[70:].abs().sum()) == 0.0
+
+
+def test_split_is_exact_and_fragment_layout():
+    torch.manual_seed(2)
+    w = torch.randn(100, 60) * torch.logspace(-6, 3, 60)[None, :]
+    b = torch.randn(100)
+    hi, mid, lo = W.split3(w)
+    assert hi.dtype == mid.dtype == lo.dtype == torch.bfloat16
+    back = hi.double() + mid.double() + lo.double()
+    rel = ((back - w.double()).abs() / w.double().abs().clamp_min(1e-30)).max()
+    assert float(rel) <= 2.0 ** -22, float(rel)          # three 8-bit significands
+    frag, bp = W.pack_split(w, b)
+    coutp, cinp = W.coutp_for(100), W.pad_to(60, 16)
+    assert frag.shape == (coutp // 32, cinp // 16, 3, 64, 8) and frag.dtype == torch.bfloat16
+    planes = [torch.zeros(coutp, cinp, dtype=torch.bfloat16) for _ in range(3)]
+    for p, t in zip(planes, (hi, mid, lo)):
+        p[:100, :60] = t
+    for nt, kb, lane, j in ((0, 0, 0, 0), (1, 2, 37, 5), (3, 3, 63, 7), (2, 1, 31, 4)):
+        for pl in range(3):
+            assert frag[nt, kb, pl, lane, j] == planes[pl][nt * 32 + (lane & 31), kb * 16 + 8 * (lane >> 5) + j]
+
+
+def test_prepare_builds_both_weight_sets():
+    from graspnet_amd import synthetic as S
+    sd = S.make_state_dict(0)
+    names = {}
+
+    class Fake(W.PackedMlp):                      # no device: keep the tensors on the host
+        def __init__(self, layers, device):
+            self.w = [w for w, _ in layers]; self.b = [b for _, b in layers]
+    orig = W.PackedMlp
+    W.PackedMlp = Fake
+    try:
+        out = W.prepare(sd, "cpu")
+    finally:
+        W.PackedMlp = orig
+    for k in ("sa1", "sa2_pre", "sa2_hoist", "fp1", "approach", "crop", "heads", "sa1_split", "sa2_hoist_split",
+              "sa4_pre_split", "fp2_split", "approach_split", "crop_split", "heads_split"):
+        assert k in out, k
+    assert out["crop_split"].w[0].dtype == torch.float32 and out["crop_split"].w[1].dtype == torch.bfloat16
+    assert out["approach_split"].w[2].shape[:2] == (384 // 32, 320 // 16)       # K padded to 320, 302 -> 384 columns
+    assert out["heads_split"].w[2].shape[0] == 2                                  # 48 -> 64 columns

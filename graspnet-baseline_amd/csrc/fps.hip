@@ -893,7 +893,8 @@ extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m,
   else if (need <= 1024 * 4) GN_FPS_LAUNCH(1024, 4);
   else if (need <= 1024 * 8) GN_FPS_LAUNCH(1024, 8);
   else if (need <= 1024 * 12) GN_FPS_LAUNCH(1024, 12);
-  else if (need <= 1024 * 16) GN_FPS_LAUNCH(1024, 16);
+  // 12 288 < need <= 16 384: the region / spatial kernels below (they track ties, so SA2-4 can short-circuit)
+  else if (need <= 1024 * 16 && !(need > 1024 * 12 && (variant == 4 || variant == 3))) GN_FPS_LAUNCH(1024, 16);
 #define GN_FPS_SPATIAL(PPT)                                                                                 \
   do {                                                                                                      \
     auto kern = fps_spatial_kernel<PPT>;                                                                    \

@@ -178,13 +178,17 @@ __device__ __forceinline__ void run_layer_stream_split_t(const void *__restrict_
   constexpr int WN = C::WN, NTW = C::NTW, MTW = C::MTW, KBC = C::KBC, NCH = C::NCH;
   const int wm = wave / WN, wn = wave % WN;
   asm volatile("" : "+s"(wq));   // keep this layer's own chunk loads below the barrier that precedes it
-  f32x16 acc[MTW][NTW];
+  // two accumulators per tile (mlp_split.h mfma6_2acc): the large products round once per 16-k block, the small ones apart
+  f32x16 acc[MTW][NTW], accl[MTW][NTW];
 #pragma unroll
   for (int i = 0; i < NTW; ++i)
 #pragma unroll
     for (int mi = 0; mi < MTW; ++mi)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][i][r] = bias.v[i][r];
+      for (int r = 0; r < 16; ++r) {
+        acc[mi][i][r] = bias.v[i][r];
+        accl[mi][i][r] = 0.f;
+      }
   StreamChunk<TP, CINP, COUTP> first, other;
   first.load(wq, 0, wave, lane);
 #pragma unroll 2
@@ -206,7 +210,8 @@ __device__ __forceinline__ void run_layer_stream_split_t(const void *__restrict_
       for (int kb = 0; kb < KBC; ++kb)
 #pragma unroll
         for (int i = 0; i < NTW; ++i)
-          acc[mi][i] = (c & 1) ? mfma6<true>(a[kb], other.v[i][kb], acc[mi][i]) : mfma6<true>(a[kb], first.v[i][kb], acc[mi][i]);
+          if (c & 1) mfma6_2acc<true>(a[kb], other.v[i][kb], acc[mi][i], accl[mi][i]);
+          else mfma6_2acc<true>(a[kb], first.v[i][kb], acc[mi][i], accl[mi][i]);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -214,7 +219,11 @@ __device__ __forceinline__ void run_layer_stream_split_t(const void *__restrict_
 #pragma unroll
   for (int mi = 0; mi < MTW; ++mi)
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) epi(wm * MTW + mi, wn * NTW + i, acc[mi][i]);
+    for (int i = 0; i < NTW; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][i][r] += accl[mi][i][r];
+      epi(wm * MTW + mi, wn * NTW + i, acc[mi][i]);
+    }
 }
 
 enum { PLOAD_PLAIN = 0, PLOAD_FP = 1 };

@@ -65,6 +65,23 @@ __device__ __forceinline__ f32x16 mfma6(const bf16x8 (&x)[3], const bf16x8 (&w)[
   return acc;
 }
 
+// The same six products into TWO accumulators: `hi` takes x0*w0 only -- one fp32 rounding per 16-k block -- and `lo` the
+// five small products (magnitude <= 2^-8 of hi's, so its own roundings are 2^-8 smaller still); the caller adds lo to hi
+// once, after the last k-block.  With one accumulator every one of the six MFMAs rounds at the accumulator's full
+// magnitude: 6*K/16 roundings, which is what made the K = 256..512 per-point chains 1.3-2x less accurate than the
+// torch-CPU oracle against float64 (profiles/parity_r02.json, stage_isolated_vs_f64); this form has K/16 + 1.
+template <bool AW>
+__device__ __forceinline__ void mfma6_2acc(const bf16x8 (&x)[3], const bf16x8 (&w)[3], f32x16 &hi, f32x16 &lo) {
+  constexpr int XI[5] = {2, 1, 0, 1, 0};
+  constexpr int WI[5] = {0, 1, 2, 0, 1};
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
+    lo = AW ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[WI[t]], x[XI[t]], lo, 0, 0, 0)
+            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[XI[t]], w[WI[t]], lo, 0, 0, 0);
+  hi = AW ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[0], hi, 0, 0, 0)
+          : __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], w[0], hi, 0, 0, 0);
+}
+
 // exact three-way split of four fp32 values (ReLU first if asked) into three packed bf16x4 (two dwords each).
 // Written pair-wise on purpose: one v_cvt_pk_bf16_f32 per pair and level, the bf16 pair widened back with a shift and a
 // mask, the residual by one v_pk_add_f32 -- 13 VALU per pair instead of the ~27 hipcc emits for the scalar form (it

@@ -15,6 +15,8 @@ struct SplitWeights {
   const float *b2, *b3;
 };
 
+constexpr int kCropMaxSpb = 16;   // seeds per workgroup the crop kernel's entry-count table holds (host clamps to it)
+
 template <class K>
 static int set_lds_attr(K kernel, size_t bytes, const char *name) {
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_unique_split_kernel(const fl
   // issued back to back it stalls the fetching waves for an L2 round trip per link at the top of every chunk.  So the
   // workgroup's entry counts go to LDS once, a chunk's uidx entries are requested two chunks ahead and its coordinates
   // (plus the seed's centre / rotation, whose address needs no load) one chunk ahead.
-  constexpr int MAXSPB = 16;
+  constexpr int MAXSPB = kCropMaxSpb;
   __shared__ int s_cnt[MAXSPB];
   const int s0 = blockIdx.x * spb;
   const int s_end = min(nseeds, s0 + spb);
@@ -519,7 +521,7 @@ extern "C" int gn_crop_unique_mlp_pool_split(const float *xyz, const float *seed
   static const int spb_env = []() { const char *e = getenv("GN_CROP_SPB"); return e ? atoi(e) : 0; }();
   int spb = nseeds / 512;    // seeds per workgroup (the 250 KB of resident weights are loaded once per workgroup):
   spb = spb < 1 ? 1 : (spb > 16 ? 16 : spb);   // two workgroups per CU in the grid at B=8 (16: 6380, 4: 6290 scenes/s)
-  if (spb_env > 0) spb = spb_env;
+  if (spb_env > 0) spb = spb_env > kCropMaxSpb ? kCropMaxSpb : spb_env;   // the kernel's s_cnt[] holds kCropMaxSpb seeds
   constexpr int TP = 96;
   constexpr size_t lds = 2 * (3 * TP * sp_stride(128) + 3 * TP * sp_stride(64)) + sizeof(float) * (2 * TP * lds_stride(8) + 2 * TP * 4);
   static const int pipe = []() { const char *e = getenv("GN_SPLIT_PIPE"); return e ? atoi(e) : 3; }();

@@ -473,23 +473,23 @@ def _expected_keys():
     return set(synthetic.make_state_dict(0, calibrated=False).keys())
 
 
-_DEFAULT_DECODER = None
+_DEFAULT_DECODERS = {}     # device -> GraspNet holding only the decode tables (end_points produced elsewhere)
 
 
 def pred_decode(end_points):
     """Drop-in for models/graspnet.py:77 pred_decode: list of B tensors (Ns_i, 17)."""
-    global _DEFAULT_DECODER
     priv = end_points.get("_gn")
     if priv is not None:
         model = priv["model"]
     else:
-        if _DEFAULT_DECODER is None:
-            _DEFAULT_DECODER = GraspNet()
-            _DEFAULT_DECODER.device = end_points["fp2_xyz"].device
+        dev = end_points["fp2_xyz"].device
+        model = _DEFAULT_DECODERS.get(dev)
+        if model is None:
+            model = GraspNet()
+            model.device = dev
             v, vr, dr = geometry.build_tables(300, 12)
-            _DEFAULT_DECODER._tables = (v.to(_DEFAULT_DECODER.device), vr.to(_DEFAULT_DECODER.device),
-                                        dr.to(_DEFAULT_DECODER.device))
-        model = _DEFAULT_DECODER
+            model._tables = (v.to(dev), vr.to(dev), dr.to(dev))
+            _DEFAULT_DECODERS[dev] = model
     grasps, counts = model.decode_padded(end_points)
     cnt = counts.cpu().tolist()          # the only host sync; the reference's callers sync here too (test.py:88)
     return [grasps[i, :c] for i, c in enumerate(cnt)]

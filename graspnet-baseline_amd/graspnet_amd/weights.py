@@ -9,8 +9,21 @@ import torch
 BN_EPS = 1e-5   # torch.nn.BatchNorm1d/2d default used by pytorch_utils.py:40-60, modules.py:38-39
 
 
+class Folded(tuple):
+    """(W', b') float32 as a plain 2-tuple, plus .w64: the folded weight before its rounding to float32.  The split-bf16
+    fragments are cut from .w64 (three bf16 terms hold ~27 significant bits, so the fold costs them no rounding)."""
+    def __new__(cls, w64, b64):
+        self = super().__new__(cls, (w64.float(), b64.float()))
+        self.w64 = w64
+        return self
+
+    def cols(self, lo, hi=None):
+        """the same layer restricted to input columns lo:hi (bias kept)"""
+        return Folded(self.w64[:, lo:hi], self[1].double())
+
+
 def fold_bn(w, b, sd, bn):
-    """conv (Cout,Cin[,1[,1]]) [+bias] followed by BN(eval) -> (W', b') in float64 -> float32."""
+    """conv (Cout,Cin[,1[,1]]) [+bias] followed by BN(eval) -> Folded (W', b'), computed in float64."""
     w = w.reshape(w.shape[0], -1).double()
     cout = w.shape[0]
     b = torch.zeros(cout, dtype=torch.float64) if b is None else b.double()
@@ -18,7 +31,7 @@ def fold_bn(w, b, sd, bn):
         scale = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + BN_EPS)
         w = w * scale[:, None]
         b = (b - sd[bn + ".running_mean"].double()) * scale + sd[bn + ".bias"].double()
-    return w.float(), b.float()
+    return Folded(w, b)
 
 
 def pad_to(n, m):
@@ -46,21 +59,22 @@ def pack_fragments(w, b, cinp=None, coutp=None):
 
 
 def split3(w):
-    """fp32 -> three bf16 terms with w == hi + mid + lo to ~2^-24 (each residual is exact in fp32)."""
-    hi = w.to(torch.bfloat16)
-    r = w - hi.float()
-    mid = r.to(torch.bfloat16)
-    lo = (r - mid.float()).to(torch.bfloat16)
+    """fp32 or fp64 -> three bf16 terms with w == hi + mid + lo to ~2^-27 relative (each bf16 rounding leaves a
+    residual <= 2^-9 of the term before it; the residuals are exact in the input's own precision)."""
+    hi = w.float().to(torch.bfloat16) if w.dtype == torch.float64 else w.to(torch.bfloat16)
+    r = w - hi.to(w.dtype)
+    mid = r.float().to(torch.bfloat16)
+    lo = (r - mid.to(w.dtype)).float().to(torch.bfloat16)
     return hi, mid, lo
 
 
 def pack_split(w, b, cinp=None, coutp=None):
-    """(Cout,Cin) f32 -> Wq[nt][kb][plane][lane][j] bf16 = W_plane[nt*32+(lane&31)][kb*16+8*(lane>>5)+j] (csrc/mlp_split.h),
+    """(Cout,Cin) f32 or f64 -> Wq[nt][kb][plane][lane][j] bf16 = W_plane[nt*32+(lane&31)][kb*16+8*(lane>>5)+j] (csrc/mlp_split.h),
     padded fp32 bias."""
     cout, cin = w.shape
     cinp = pad_to(cin, 16) if cinp is None else cinp
     coutp = coutp_for(cout) if coutp is None else coutp
-    wp = torch.zeros(coutp, cinp, dtype=torch.float32)
+    wp = torch.zeros(coutp, cinp, dtype=w.dtype)
     wp[:cout, :cin] = w
     bp = torch.zeros(coutp, dtype=torch.float32)
     bp[:cout] = b
@@ -98,23 +112,25 @@ def prepare(sd, device, num_view=300, num_angle=12):
         c = w0.shape[1] - 3
         # reference input order is [xyz(3) | features(C)] (pointnet2_utils.py:353); kernels use [features | xyz | pad]
         w0 = torch.cat([w0[:, 3:], w0[:, :3]], dim=1)
+        w0_64 = torch.cat([layers[0].w64[:, 3:], layers[0].w64[:, :3]], dim=1)
+        tail_split = [pack_split(l.w64, l[1]) for l in layers[1:]]
         packed = [pack_fragments(w0, b0, cinp=c + 8)] + [pack_fragments(w, b) for w, b in layers[1:]]
         out["sa%d" % (li + 1)] = PackedMlp(packed, device)
         if c == 0:   # SA1 on the matrix-core path: layer 1 (K = 3) fp32, layers 2-3 split
-            out["sa1_split"] = PackedMlp([pack_fragments(w0, b0, cinp=8)] + [pack_split(w, b) for w, b in layers[1:]], device)
+            out["sa1_split"] = PackedMlp([pack_fragments(w0, b0, cinp=8)] + tail_split, device)
         if c > 0:
             # layer 1 split for the hoisted kernel: per-point part W1f (+ bias) and per-neighbour K=8 block W1x
             out["sa%d_pre" % (li + 1)] = PackedMlp([pack_fragments(w0[:, :c], b0)], device)
-            out["sa%d_pre_split" % (li + 1)] = PackedMlp([pack_split(w0[:, :c], b0)], device)
+            out["sa%d_pre_split" % (li + 1)] = PackedMlp([pack_split(w0_64[:, :c], b0)], device)
             out["sa%d_hoist" % (li + 1)] = PackedMlp(
                 [pack_fragments(w0[:, c:], torch.zeros_like(b0), cinp=8)] + [pack_fragments(w, b) for w, b in layers[1:]],
                 device)
             out["sa%d_hoist_split" % (li + 1)] = PackedMlp(
-                [pack_fragments(w0[:, c:], torch.zeros_like(b0), cinp=8)] + [pack_split(w, b) for w, b in layers[1:]], device)
+                [pack_fragments(w0[:, c:], torch.zeros_like(b0), cinp=8)] + tail_split, device)
     for i in (1, 2):
         layers = _shared_mlp_layers(sd, "%s.fp%d.mlp" % (bb, i), 2)
         out["fp%d" % i] = PackedMlp([pack_fragments(w, b) for w, b in layers], device)
-        out["fp%d_split" % i] = PackedMlp([pack_split(w, b) for w, b in layers], device)
+        out["fp%d_split" % i] = PackedMlp([pack_split(l.w64, l[1]) for l in layers], device)
     vp = "view_estimator.vpmodule"
     nv = 2 + num_view
     l1 = fold_bn(sd[vp + ".conv1.weight"], sd[vp + ".conv1.bias"], sd, vp + ".bn1")
@@ -124,12 +140,12 @@ def prepare(sd, device, num_view=300, num_angle=12):
     out["approach"] = PackedMlp([pack_fragments(*l1), pack_fragments(*l2, coutp=nvp),
                                  pack_fragments(*l3, cinp=pad_to(nv, 32), coutp=nvp)], device)   # K padded to 320: chunks of 80
     crop_layers = _shared_mlp_layers(sd, "grasp_generator.crop.mlps", 3)
-    out["approach_split"] = PackedMlp([pack_split(*l1), pack_split(*l2, coutp=nvp),
-                                       pack_split(*l3, cinp=pad_to(nv, 32), coutp=nvp)], device)
+    out["approach_split"] = PackedMlp([pack_split(l1.w64, l1[1]), pack_split(l2.w64, l2[1], coutp=nvp),
+                                       pack_split(l3.w64, l3[1], cinp=pad_to(nv, 32), coutp=nvp)], device)
     out["crop"] = PackedMlp([pack_fragments(w, b, cinp=8 if i == 0 else None) for i, (w, b) in enumerate(crop_layers)], device)
     # layers 2-3 as split-bf16 fragments for the matrix-core path (layer 1, K = 3, stays fp32)
-    out["crop_split"] = PackedMlp([pack_fragments(*crop_layers[0], cinp=8), pack_split(*crop_layers[1]),
-                                   pack_split(*crop_layers[2])], device)
+    out["crop_split"] = PackedMlp([pack_fragments(*crop_layers[0], cinp=8), pack_split(crop_layers[1].w64, crop_layers[1][1]),
+                                   pack_split(crop_layers[2].w64, crop_layers[2][1])], device)
     # OperationNet + ToleranceNet as one chain: conv1 stacked, conv2 / conv3 block-diagonal
     op, tl = "grasp_generator.operation", "grasp_generator.tolerance"
     o1 = fold_bn(sd[op + ".conv1.weight"], sd[op + ".conv1.bias"], sd, op + ".bn1")
@@ -146,5 +162,8 @@ def prepare(sd, device, num_view=300, num_angle=12):
     w3 = torch.zeros(no + nt_, 2 * h); w3[:no, :h] = o3[0]; w3[no:, h:] = t3[0]
     b3 = torch.cat([o3[1], t3[1]], 0)
     out["heads"] = PackedMlp([pack_fragments(w1, b1), pack_fragments(w2, b2), pack_fragments(w3, b3)], device)
-    out["heads_split"] = PackedMlp([pack_split(w1, b1), pack_split(w2, b2), pack_split(w3, b3)], device)
+    w1d = torch.cat([o1.w64, t1.w64], 0)
+    w2d = torch.zeros(2 * h, 2 * h, dtype=torch.float64); w2d[:h, :h] = o2.w64; w2d[h:, h:] = t2.w64
+    w3d = torch.zeros(no + nt_, 2 * h, dtype=torch.float64); w3d[:no, :h] = o3.w64; w3d[no:, h:] = t3.w64
+    out["heads_split"] = PackedMlp([pack_split(w1d, b1), pack_split(w2d, b2), pack_split(w3d, b3)], device)
     return out

@@ -123,6 +123,7 @@ def backbone(pointcloud, sd, end_points, dt=torch.float32):
         end_points["sa%d_features" % (li + 1)] = features
     f = fp_module(end_points["sa3_xyz"], end_points["sa4_xyz"], end_points["sa3_features"],
                   end_points["sa4_features"], sd, p + ".fp1")
+    end_points["_fp1_features"] = f            # private (not a reference key): stage-level error attribution
     f = fp_module(end_points["sa2_xyz"], end_points["sa3_xyz"], end_points["sa2_features"], f, sd, p + ".fp2")
     end_points["fp2_features"] = f
     end_points["fp2_xyz"] = end_points["sa2_xyz"]

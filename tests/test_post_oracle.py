@@ -38,3 +38,28 @@ def test_nms_suppresses_near_duplicates():
     g[2, 13] = 1.0                                      # far away -> kept
     out = PO.nms_grasp(g, 0.03, np.pi / 6)
     assert len(out) == 2 and out[0, 0] == np.float32(0.9) and out[1, 0] == np.float32(0.1)
+
+
+def test_collision_detect_matches_reference_detect(golden_dir):
+    """oracle/post_oracle.collision_detect == the REFERENCE's ModelFreeCollisionDetector.detect
+    (utils/collision_detector.py:36-129) run in the build container by tests/golden/make_golden_collision.py:
+    both masks and the five IoUs, bit for bit, for three caller settings incl. a zero-width grasp."""
+    import importlib.util
+    import os
+    from oracle import post_oracle as PO
+    spec = importlib.util.spec_from_file_location("make_golden_collision", os.path.join(golden_dir, "make_golden_collision.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    cloud, rows = mg.inputs(golden_dir)
+    z = np.load(os.path.join(golden_dir, "collision_ref.npz"))
+    assert int(z["n_grasps"][0]) == len(rows)
+    for ci in range(len(mg.CASES)):
+        ad, ct, et, vs = (float(v) for v in z["case%d/params" % ci])
+        scene = PO.voxel_down_sample(cloud, vs)
+        assert len(scene) == int(z["case%d/n_scene" % ci][0])
+        with np.errstate(all="ignore"):
+            cm, em, ious = PO.collision_detect(scene, rows, approach_dist=ad, collision_thresh=ct, empty_thresh=et, voxel_size=vs)
+        assert np.array_equal(cm, z["case%d/collision_mask" % ci]) and np.array_equal(em, z["case%d/empty_mask" % ci])
+        for name, v in zip(("global", "left", "right", "bottom", "shifting"), ious):
+            assert np.array_equal(v, z["case%d/iou_%s" % (ci, name)], equal_nan=True), (ci, name)
+        assert 0 < int(cm.sum()) < len(rows)

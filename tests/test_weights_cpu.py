@@ -72,3 +72,17 @@ def test_prepare_builds_both_weight_sets():
     assert out["crop_split"].w[0].dtype == torch.float32 and out["crop_split"].w[1].dtype == torch.bfloat16
     assert out["approach_split"].w[2].shape[:2] == (384 // 32, 320 // 16)       # K padded to 320, 302 -> 384 columns
     assert out["heads_split"].w[2].shape[0] == 2                                  # 48 -> 64 columns
+
+
+def test_split_of_float64_fold_keeps_more_than_fp32():
+    """the split fragments are cut from the float64 BN fold: hi+mid+lo reproduces it to ~2^-26, i.e. better than the
+    fold rounded to float32 (2^-24) -- the fold costs the matrix-core path no rounding"""
+    torch.manual_seed(3)
+    w64 = torch.randn(64, 48, dtype=torch.float64) * torch.logspace(-3, 2, 48, dtype=torch.float64)[None, :]
+    hi, mid, lo = W.split3(w64)
+    back = hi.double() + mid.double() + lo.double()
+    rel = ((back - w64).abs() / w64.abs()).max()
+    rel32 = ((w64.float().double() - w64).abs() / w64.abs()).max()
+    assert float(rel) <= 2.0 ** -25 and float(rel) < float(rel32)
+    f = W.Folded(w64, torch.zeros(64, dtype=torch.float64))
+    assert f[0].dtype == torch.float32 and f.w64.dtype == torch.float64 and torch.equal(f[0], w64.float())

@@ -8,13 +8,18 @@ resident in HBM -> GraspNet.forward (4xSA, 2xFP, ApproachNet, CloudCrop, heads) 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel, timed live with HIP events on
-the launch stream inside the timed region; `cpu_baseline` is the oracle port timed on this host
-(rank 0, N=1 only, bounded sample).
+Rank 0 prints ONE JSON line.  `value` is the headline leg: K timed steps issued round-robin on `--streams`
+HIP streams over 4 distinct sets of 8 `uniform` clouds, nothing but the product path inside the
+timed region.  Beside it (N=1 only, each its own timed leg AFTER the headline): the same on `surface` clouds
+(duplicate points -> FPS ties -> the SA2-4 samplers really run), the single-stream rate (what a caller looping
+`net(batch)` gets), the GN_MATH=f32 rate, and the hipGraph-replayed latency at B=1 and B=8.  `roofline` is for
+the dominant kernel, timed with HIP events on its launch stream in an isolated single-stream pass;
+`cpu_baseline` is the oracle port timed on this host (rank 0, N=1 only, bounded sample).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -38,11 +43,34 @@ FLOP_PER_SCENE = {"sa1": 3.272e9, "sa2": 4.320e9, "sa3": 1.348e9, "sa4": 0.674e9
 PEAK_F32_MFMA = 157.3e12     # MI355X_MICROARCH.md chip table (v_mfma_f32_32x32x2_f32: the SIMDs' FP32 ALUs)
 PEAK_BF16_MFMA = 2.5e15      # dense bf16 matrix-core peak, same table
 PEAK_HBM = 8.0e12
+CROP_FLOP_PER_ROW_SPLIT = 81920.0 * 6.0   # layers 2-3 (64->128->256): 6 bf16 products per fp32 MAC (csrc/mlp_split.h)
+CROP_FLOP_PER_ROW_F32 = 82944.0           # all three layers as fp32 MACs
+NSETS = 4                                  # distinct 8-cloud sets the timed steps rotate over
 
 
-def cpu_baseline(n_scenes, n_points):
-    """Oracle port (C operators with OpenMP + torch-CPU MLPs) on this host: the reference has no
-    CPU PointNet++ path of its own, so this is kind='port'."""
+def log(msg):
+    """progress on stderr (stdout carries the ONE JSON line): a run cut short says how far it got"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(n_points, reps1, reps8):
+    """Oracle port (C operators with OpenMP + torch-CPU MLPs) on this host: the reference has no CPU PointNet++
+    path of its own, so this is kind='port'.  SURVEY.md 8d: warm-up 2, median of 10, on config[0]
+    (one cloud per call) and config[1] (batch 8 per call; fewer repetitions to stay within ~30 s)."""
     from oracle import model_oracle as MO, oracle as O
     from graspnet_amd import synthetic as S
     O.build()
@@ -51,22 +79,49 @@ def cpu_baseline(n_scenes, n_points):
     O.set_num_threads(cores)
     torch.set_num_threads(cores)
     sd = S.make_state_dict(0)
-    clouds = S.make_batch(1000, n_scenes, n_points)
-    MO.pred_decode(MO.forward({"point_clouds": clouds[:1].clone()}, sd))      # warm-up
-    t0 = time.time()
-    for i in range(n_scenes):
-        MO.pred_decode(MO.forward({"point_clouds": clouds[i:i + 1].clone()}, sd))
-    dt = time.time() - t0
-    return {"value": n_scenes / dt, "unit": "scenes/s", "cores": cores, "kind": "port",
-            "sample": "%d scenes x %d pts, B=1 per call, oracle C ops (OpenMP) + torch-CPU MLPs, %.1f s" % (n_scenes, n_points, dt)}
+    clouds = S.make_batch(1000, 8, n_points)
+
+    def timed(batch, warm, reps):
+        for _ in range(warm):
+            MO.pred_decode(MO.forward({"point_clouds": batch.clone()}, sd))
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            MO.pred_decode(MO.forward({"point_clouds": batch.clone()}, sd))
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), sum(ts)
+
+    t_all = time.perf_counter()
+    m1, _ = timed(clouds[:1], 2, reps1)
+    m8, _ = timed(clouds, 1, reps8)
+    total = time.perf_counter() - t_all
+    return {"value": 8.0 / m8, "unit": "scenes/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "config0_scenes_per_s": 1.0 / m1,
+            "sample": "oracle C ops (OpenMP) + torch-CPU MLPs, %d threads: config[1] batch 8 x %d pts per call, warm-up 1, "
+                      "median of %d calls (%.2f s each) -> value; config[0] one cloud per call, warm-up 2, median of %d "
+                      "(%.3f s each); %.0f s in all" % (cores, n_points, reps8, m8, reps1, m1, total)}
+
+
+def pmc_file():
+    """The committed PMC passes of the bench command (HBM bytes per launch); newest round first."""
+    for name in ("r2_pmc_traffic.json", "r1g_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                return name, json.load(open(path))
+            except ValueError:
+                pass
+    return None, {}
 
 
 def op_rooflines(dev, reps=20):
-    """HBM-bound drop-in operators at SA sizes (B=8): algorithmic bytes / HIP-event time."""
+    """The drop-in operators BASELINE.json's metric names, at SA sizes (B=8): algorithmic bytes / HIP-event
+    time, against the 8 TB/s HBM peak; PMC bytes per launch beside them where a committed pass has them."""
     from graspnet_amd import pointnet2_ext as E, synthetic as S
     out = {}
     xyz = S.make_batch(1000, 8, 20000).to(dev)
     ctr = xyz[:, :2048].contiguous()
+    _, pmc = pmc_file()
 
     def timed(fn):
         fn()
@@ -78,19 +133,27 @@ def op_rooflines(dev, reps=20):
         torch.cuda.synchronize()
         return a.elapsed_time(b) / reps * 1e-3
 
+    def rec(name, nbytes, t, bound, **extra):
+        r = {"bytes": nbytes, "ms": t * 1e3, "GBps": nbytes / t / 1e9, "frac_hbm": nbytes / t / PEAK_HBM, "bound": bound,
+             "pmc_bytes": pmc.get(name, {}).get("traffic_bytes")}
+        r.update(extra)
+        out[name] = r
+
     t = timed(lambda: E.ball_query(ctr, xyz, 0.04, 64))
-    out["ball_query_sa1"] = {"bytes": 788864 * 8, "ms": t * 1e3, "GBps": 788864 * 8 / t / 1e9, "frac_hbm": 788864 * 8 / t / PEAK_HBM,
-                             "tests_per_s": 8 * 2048 * 20000 / t, "bound": "VALU issue (brute force), not HBM"}
+    rec("ball_query_sa1", 788864 * 8, t, "latency / VALU issue (grid cells then a sorted 64-lane register), HBM-trivial",
+        tests_per_s_brute_force_equivalent=8 * 2048 * 20000 / t)
     feat = torch.rand(8, 128, 2048, device=dev)
     idx = torch.randint(0, 2048, (8, 1024, 32), device=dev, dtype=torch.int32)
     t = timed(lambda: E.group_points(feat, idx))
-    out["group_points_sa2"] = {"bytes": 17956864 * 8, "ms": t * 1e3, "GBps": 17956864 * 8 / t / 1e9, "frac_hbm": 17956864 * 8 / t / PEAK_HBM,
-                               "bound": "hbm (write)"}
+    rec("group_points_sa2", 17956864 * 8, t, "hbm (write)")
     xt = xyz.transpose(1, 2).contiguous()
     idx1 = torch.randint(0, 20000, (8, 2048, 64), device=dev, dtype=torch.int32)
     t = timed(lambda: E.group_points(xt, idx1))
-    out["group_points_sa1"] = {"bytes": 2337152 * 8, "ms": t * 1e3, "GBps": 2337152 * 8 / t / 1e9, "frac_hbm": 2337152 * 8 / t / PEAK_HBM,
-                               "bound": "hbm (write)"}
+    rec("group_points_sa1", 2337152 * 8, t, "hbm (write)")
+    rot = torch.eye(3, device=dev).reshape(1, 1, 9).repeat(8, 1024, 1).contiguous()
+    seeds = xyz[:, :1024].contiguous()
+    t = timed(lambda: E.cylinder_query(seeds, xyz, rot, 0.05, -0.02, 0.04, 64))
+    rec("cylinder_query", 551296 * 8, t, "latency / VALU issue, HBM-trivial")
     return out
 
 
@@ -107,12 +170,22 @@ def main():
     ap.add_argument("--streams", type=int, default=12,
                     help="HIP streams the steps are issued round-robin on (FPS is a serial chain on 8 CUs per "
                          "batch; other batches' kernels fill the rest of the chip meanwhile)")
+    ap.add_argument("--variant", default="uniform", choices=("uniform", "surface"), help="synthetic clouds of the headline leg")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse the N>1 code "
                          "path with several ranks sharing one GPU)")
+    ap.add_argument("--legs", default="all",
+                    help="all | headline (only the timed headline leg + the isolated per-kernel pass: what the rocprofv3 passes "
+                         "run) | comma list of the legs beside the headline: single,other,f32,graph,ops,cpu")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-scenes", type=int, default=16)
+    ap.add_argument("--cpu-reps", type=int, default=10, help="timed config[0] calls of the CPU baseline (config[1]: a third)")
     args = ap.parse_args()
+    all_legs = {"single", "other", "f32", "graph", "ops", "cpu"}
+    legs = all_legs if args.legs == "all" else (set() if args.legs == "headline" else set(args.legs.split(",")))
+    if not legs <= all_legs:
+        raise SystemExit("--legs: unknown leg in %r" % (args.legs,))
+    if args.no_cpu_baseline:
+        legs.discard("cpu")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -130,10 +203,11 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
 
-    from graspnet_amd import GraspNet, synthetic as S
+    from graspnet_amd import GraspNet, GraphedGraspNet, synthetic as S
     from graspnet_amd import dist as gdist
     B, N = args.batch, args.points
-    net = GraspNet(is_training=False, device=dev).load_state_dict(S.make_state_dict(0))
+    sd = S.make_state_dict(0)
+    net = GraspNet(is_training=False, device=dev).load_state_dict(sd)
     # weak scaling: every rank owns its own B scenes (global batch = world*B, contiguous shards);
     # strong scaling (--global-batch G): the same G scenes however many ranks share them
     if args.global_batch:
@@ -141,107 +215,155 @@ def main():
             raise SystemExit("--global-batch must be a multiple of the number of ranks (equal shards for the all-gather)")
         lo, hi = gdist.shard_range(args.global_batch, rank, world)
         B = hi - lo
+        gb = args.global_batch
     else:
-        lo, _ = gdist.shard_range(world * B, rank, world)
-    clouds = S.make_batch(1000 + lo, B, N, "uniform").to(dev)
+        gb = world * B
+        lo, _ = gdist.shard_range(gb, rank, world)
 
+    def cloud_sets(variant):
+        """NSETS distinct global batches; this rank's contiguous shard of each (scene s of set j: seed 1000 + j*gb + s)"""
+        return [S.make_batch(1000 + j * gb + lo, B, N, variant).to(dev) for j in range(NSETS)]
+
+    sets = cloud_sets(args.variant)
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
-    # torch's caching allocator keeps one pool per stream: reserve each stream's pool up front (setup, like creating the
-    # streams) so that a stream's first step does not spend its time in hipMalloc when --warmup is smaller than --streams
-    per_step = 6 * B * (N * 12 + 4 * 1024 * 1024)        # ~2x the outputs + workspace of one step (0.2 GB at B=8)
-    for st in streams:
-        with torch.cuda.stream(st):
-            blk = torch.empty((per_step,), dtype=torch.uint8, device=dev)
-            del blk
-    torch.cuda.synchronize()
+    gatherer = gdist.GraspGatherer(dev) if world > 1 else None
 
-    last = {}
+    def run_steps(model, batches, strms, nsteps, gather=True):
+        last = None
+        for i in range(nsteps):
+            with torch.cuda.stream(strms[i % len(strms)]):
+                ep = model({"point_clouds": batches[i % len(batches)]})
+                g, c = model.decode_padded(ep)
+                if gather and gatherer is not None:
+                    # the all-gather runs on the gatherer's side stream behind an event, so this stream goes straight on
+                    # to its next batch (SURVEY.md 8e); the final synchronize covers it
+                    g, c, _ = gatherer.gather(g, c)
+            last = (ep, g, c)
+        return last
 
-    def step(i):
-        with torch.cuda.stream(streams[i % len(streams)]):
-            ep = net({"point_clouds": clouds})
-            g, c = net.decode_padded(ep)
-            if world > 1:
-                g, c = gdist.all_gather_grasps(g, c)
-        last["ep"] = ep
-        return g, c
+    def timed_leg(model, batches, strms, nsteps, warm):
+        """warm: untimed steps (at least one per stream, so no stream meets its first kernels, allocator pool or code
+        objects inside the timed region); then EXACTLY nsteps between barrier+synchronize brackets; max over ranks"""
+        run_steps(model, batches, strms, max(warm, len(strms)))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        last = run_steps(model, batches, strms, nsteps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        per_rank = [elapsed]
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            per_rank = [float(x.item()) for x in allt]
+            elapsed = max(per_rank)
+        return elapsed, per_rank, last
 
-    for i in range(args.warmup):
-        step(i)
-    net.timing = {}          # HIP-event brackets around every kernel launch, recorded in the timed region
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        g, c = step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    log("setup done: B=%d N=%d world=%d streams=%d" % (B, N, world, len(streams)))
+    # ---- headline leg: nothing but the product path in the timed region (no per-kernel events, no hooks)
+    net.timing = None
+    elapsed, per_rank, last = timed_leg(net, sets, streams, args.steps, args.warmup)
+    last_ep, _, c = last
+    grasps_last = int(c.sum().item())
 
     def averages(timing):
         return {name: sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1) for name, evs in timing.items()}
 
-    overlapped = averages(net.timing)          # inside the timed region: kernels of up to `streams` batches overlap
-    # isolated pass (outside the timed region): the same steps on ONE stream, so a kernel's event bracket is
-    # its own duration -- these feed the per-kernel roofline; rocprofv3 of `--streams 1` matches them
+    log("headline leg: %.3f ms/step" % (elapsed / args.steps * 1e3))
+    # ---- isolated pass (outside every timed region): the same steps on ONE stream with HIP-event brackets around every
+    # kernel launch on that stream, so a bracket is the kernel's own duration -- these feed the per-kernel roofline;
+    # rocprofv3 --kernel-trace of `--streams 1 --legs headline` agrees with them (profiles/)
     net.timing = {}
-    for i in range(min(args.steps, 10)):
-        with torch.cuda.stream(streams[0]):
-            ep = net({"point_clouds": clouds})
-            net.decode_padded(ep)
+    run_steps(net, sets, streams[:1], min(args.steps, 12), gather=False)
     torch.cuda.synchronize()
+    stages = averages(net.timing)
+    net.timing = None
+
+    log("isolated per-kernel pass done")
+    extra = {}
+    k1 = max(10, min(args.steps, 40))
+    if world == 1 and "single" in legs:
+        e1, _, _ = timed_leg(net, sets, streams[:1], k1, 3)
+        extra["single_stream_scenes_per_s"] = B * k1 / e1
+        extra["single_stream_ms_per_step"] = e1 / k1 * 1e3
+        log("single-stream leg: %.3f ms/step" % (e1 / k1 * 1e3))
+    if world == 1 and "other" in legs:
+        other = "surface" if args.variant == "uniform" else "uniform"
+        osets = cloud_sets(other)
+        e2, _, l2 = timed_leg(net, osets, streams, args.steps, args.warmup)
+        e2s, _, _ = timed_leg(net, osets, streams[:1], k1, 3)
+        extra["%s_clouds" % other] = {"scenes_per_s": B * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3,
+                                      "single_stream_scenes_per_s": B * k1 / e2s, "steps": args.steps,
+                                      "grasps_last_step": int(l2[2].sum().item()),
+                                      "note": "%d distinct sets of %d `%s` clouds; surface scenes contain duplicate points, so "
+                                              "SA1's sampler meets exact ties and SA2-4 run their full FPS chains" % (NSETS, B, other)}
+        del osets
+        log("%s legs done" % other)
+    if world == 1 and "f32" in legs and net.math_split:
+        if True:
+            net32 = GraspNet(is_training=False, device=dev).load_state_dict(sd)
+            net32.math_split = False
+            k3 = max(10, min(args.steps, 50))
+            e3, _, _ = timed_leg(net32, sets, streams, k3, args.warmup)
+            extra["gn_math_f32_scenes_per_s"] = B * k3 / e3
+            del net32
+        log("f32 leg done")
+    if world == 1 and "graph" in legs:
+        lat = {}
+        for gbatch in sorted({1, B}):
+            gnet = GraphedGraspNet(net, batch=gbatch, points=N)
+            x = sets[0][:gbatch]
+            for _ in range(3):
+                gnet(x)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ts = []
+            for _ in range(20):
+                a.record()
+                gnet(x)
+                b.record()
+                b.synchronize()
+                ts.append(a.elapsed_time(b))
+            lat["B=%d" % gbatch] = statistics.median(ts)
+            del gnet
+        extra["hipgraph_latency_ms"] = lat
+        log("hipGraph latency legs done: %s" % lat)
+
     if rank == 0:
-        last_ep = last.get("ep", {})
-        stages = averages(net.timing)
-        net.timing = None
         # dominance by CU-time: FPS is the longest kernel but runs on B of the 256 CUs
         cu_share = {k: (B / 256.0 if k.startswith("furthest_point_sampling") else 1.0) for k in stages}
         dom = max(stages, key=lambda k: stages[k] * cu_share[k]) if stages else None
         rk = "crop_unique_mlp_pool" if "crop_unique_mlp_pool" in stages else "crop_group_mlp_pool"
         roof = None
-        if rk in stages and N == 20000:
+        uc = last_ep.get("_gn", {}).get("ucount")
+        if rk in stages and N == 20000 and uc is not None:
             sec = stages[rk] * 1e-3
-            ach = FLOP_PER_SCENE["crop"] * B / sec          # SURVEY.md 8d algorithmic figure x scenes per launch
-            roof = {"bound": "mfma", "kernel": rk, "achieved": ach / 1e12, "peak": PEAK_F32_MFMA / 1e12,
-                    "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA, "traffic": None, "avg_launch_ms": stages[rk],
-                    "avg_launch_ms_in_timed_region": overlapped.get(rk),
-                    "measured": "HIP events on the launch stream; avg_launch_ms from a single-stream pass of the same "
-                                "steps right after the timed region (inside it, kernels of up to %d batches share the "
-                                "chip and a launch's bracket includes that contention)" % len(streams)}
-            # HBM traffic of this kernel cannot be counted from inside the process: it comes from the committed PMC passes
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r1g_pmc_traffic.json")))[rk]
-                if net.math_split and B == 8:
-                    roof["traffic"] = pmc["traffic_bytes"]
-                    roof["traffic_source"] = "profiles/r1g_pmc_traffic.json: " + pmc["how"]
-            except (OSError, KeyError, ValueError):
-                pass
-            uc = last_ep.get("_gn", {}).get("ucount")
-            if uc is not None:
-                # the de-duplicated path executes fewer MACs than the reference algorithm: report the
-                # MFMA work actually issued too (rows padded to 32-row tiles x 82,944 FLOP per row)
-                rows = int((((uc + 31) // 32) * 32).sum().item())
-                ex = rows * 82944.0 / sec
-                roof["executed"] = {"f32_equiv_tflops": ex / 1e12, "rows_per_seed": rows / float(uc.numel()),
-                                    "note": "algorithmic 'achieved' counts the reference's 4x64 rows per seed; the "
-                                            "kernel evaluates each unique (seed,point) row once"}
-                if net.math_split:
-                    # layers 2-3 (81,920 of the 82,944 FLOP per row) run as 6 bf16 products per fp32 MAC on the matrix cores
-                    exb = rows * 81920.0 * 6.0 / sec
-                    roof["executed"].update({"bf16_mfma_tflops": exb / 1e12, "frac_of_bf16_mfma_peak": exb / PEAK_BF16_MFMA,
-                                             "bf16_mfma_peak_tflops": PEAK_BF16_MFMA / 1e12})
-                    roof["note"] = ("fp32 results from the bf16 matrix cores: each operand split exactly into 3 bf16 terms, 6 "
-                                    "products per MAC, fp32 accumulate (csrc/mlp_split.h); 'achieved'/'frac' are fp32-equivalent "
-                                    "algorithmic FLOP/s against the fp32 MFMA peak and exceed 1 because the fp32 MFMA is not the "
-                                    "unit doing the work; 'executed' prices the issued bf16 MFMAs against the bf16 peak")
-                else:
-                    roof["executed"]["frac_of_peak"] = ex / PEAK_F32_MFMA
+            # MFMA work the kernel issues per launch: every unique (seed, point) row once, padded to 32-row tiles
+            rows = int((((uc + 31) // 32) * 32).sum().item())
+            alg = FLOP_PER_SCENE["crop"] * B          # SURVEY.md 8d: the reference's 4 x 64 rows per seed, fp32 MACs
+            pmc_name, pmc = pmc_file()
+            traffic = pmc.get(rk, {}) if (net.math_split and B == 8) else {}
+            if net.math_split:
+                issued, peak, unit_note = rows * CROP_FLOP_PER_ROW_SPLIT, PEAK_BF16_MFMA, "bf16 MFMA (v_mfma_f32_32x32x16_bf16)"
+            else:
+                issued, peak, unit_note = rows * CROP_FLOP_PER_ROW_F32, PEAK_F32_MFMA, "fp32 MFMA (v_mfma_f32_32x32x2_f32)"
+            roof = {"bound": "mfma", "kernel": rk, "achieved": issued / sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+                    "frac": issued / sec / peak, "traffic": traffic.get("traffic_bytes"),
+                    "priced": "issued %s FLOP per launch = %d padded unique rows x %.0f, against that unit's dense peak"
+                              % (unit_note, rows, issued / rows),
+                    "avg_launch_ms": stages[rk], "rows_per_seed": rows / float(uc.numel()),
+                    "algorithmic": {"flop_per_launch": alg, "f32_equiv_tflops": alg / sec / 1e12,
+                                    "x_f32_mfma_peak": alg / sec / PEAK_F32_MFMA,
+                                    "note": "SURVEY.md 8d figure (21.576 GFLOP/scene: the reference evaluates 4 x 64 rows per seed as "
+                                            "fp32 MACs) / the same launch time; a rate of useful work, not a fraction of any unit's "
+                                            "peak: the kernel evaluates each unique row once and splits each fp32 MAC into 6 bf16 products"},
+                    "measured": "HIP events on the launch stream, single-stream pass right after the timed region"}
+            if traffic:
+                roof["traffic_source"] = "profiles/%s: %s" % (pmc_name, traffic.get("how", ""))
         mlp_ms = sum(v for k, v in stages.items() if "mlp" in k)
         mlp_flop = sum(FLOP_PER_SCENE.values()) * B if N == 20000 else None
         out = {
@@ -253,22 +375,24 @@ def main():
             "dtype": ("f32 (grouped layers: exact 3xbf16 operand split, 6 bf16 MFMA products per MAC, fp32 accumulate)"
                       if net.math_split else "f32"),
             "data": "synthetic",
-            "config": {"workload": "config[1]: batch %d x %d-pt synthetic clouds per GPU, full SA->ApproachNet->"
-                                   "CloudCrop->OperationNet/ToleranceNet->pred_decode, seeded random weights" % (B, N),
+            "config": {"workload": "config[1]: batch %d x %d-pt synthetic `%s` clouds per GPU (%d distinct sets in rotation), full "
+                                   "SA->ApproachNet->CloudCrop->OperationNet/ToleranceNet->pred_decode, seeded random weights"
+                                   % (B, N, args.variant, NSETS),
                        "batch_per_gpu": B, "points": N, "parallelism": "scene shards x%d" % world,
-                       "streams": len(streams)},
+                       "streams": len(streams), "warmup_steps_run": max(args.warmup, len(streams))},
             "roofline": roof,
+            "per_rank_ms_per_step": {"min": min(per_rank) / args.steps * 1e3, "max": max(per_rank) / args.steps * 1e3,
+                                     "all": [round(t / args.steps * 1e3, 4) for t in per_rank]},
             "dominant_kernel_by_cu_time": dom,
             "all_mlp_kernels": {"ms": mlp_ms, "algorithmic_tflops": (mlp_flop / (mlp_ms * 1e-3) / 1e12) if mlp_flop and mlp_ms else None},
-            "op_rooflines": op_rooflines(dev) if world == 1 else None,
+            "op_rooflines": op_rooflines(dev) if (world == 1 and "ops" in legs) else None,
             "kernel_ms": {k: round(v, 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])},
-            "kernel_ms_in_timed_region": {k: round(v, 4) for k, v in sorted(overlapped.items(), key=lambda kv: -kv[1])},
-            "end_to_end": {"algorithmic_mlp_tflops": (sum(FLOP_PER_SCENE.values()) * world * B * args.steps / elapsed / 1e12) if N == 20000 else None,
-                           "frac_of_f32_mfma_peak": (sum(FLOP_PER_SCENE.values()) * B * args.steps / elapsed / PEAK_F32_MFMA) if N == 20000 else None},
-            "grasps_last_step": int(c.sum().item()),
+            "grasps_last_step": grasps_last,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_scenes, N)
+        out.update(extra)
+        log("op rooflines done; cpu baseline next")
+        if world == 1 and "cpu" in legs:
+            out["cpu_baseline"] = cpu_baseline(N, args.cpu_reps, max(1, args.cpu_reps // 3))
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

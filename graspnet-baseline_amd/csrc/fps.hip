@@ -395,7 +395,7 @@ __global__ __launch_bounds__(1024) void fps_spatial_kernel(const float *__restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// Region-interleaved variant (the default for 12 288 < positions <= 20 480).
+// Region-interleaved variant (the default for 16 384 < positions <= 20 480).
 //
 // fps_spatial_kernel skips whole waves, but the waves that do run still pay for all their points,
 // and an iteration lasts as long as its busiest wave.  Here the cloud is cut into 64 regions of
@@ -893,8 +893,7 @@ extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m,
   else if (need <= 1024 * 4) GN_FPS_LAUNCH(1024, 4);
   else if (need <= 1024 * 8) GN_FPS_LAUNCH(1024, 8);
   else if (need <= 1024 * 12) GN_FPS_LAUNCH(1024, 12);
-  // 12 288 < need <= 16 384: the region / spatial kernels below (they track ties, so SA2-4 can short-circuit)
-  else if (need <= 1024 * 16 && !(need > 1024 * 12 && (variant == 4 || variant == 3))) GN_FPS_LAUNCH(1024, 16);
+  else if (need <= 1024 * 16) GN_FPS_LAUNCH(1024, 16);
 #define GN_FPS_SPATIAL(PPT)                                                                                 \
   do {                                                                                                      \
     auto kern = fps_spatial_kernel<PPT>;                                                                    \
@@ -920,9 +919,10 @@ extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m,
     hipLaunchKernelGGL(kern, dim3(b), dim3(512), lds, s, xyz, n, m, bs, lg, Q, qmagic, idx, new_xyz, tie_out); \
     tie_written = true;                                                                                     \
   } while (0)
-  else if (need > 1024 * 12 && need <= 1024 * 16 && variant == 4) GN_FPS_REGION(32);
+  // the region / spatial kernels (tie tracking -> SA2-4 prefix shortcut) serve 16 384 < need <= 20 480, i.e. the model's
+  // 20 000-point level; up to 16 384 positions the register kernel above runs and reports "tie unknown" (memset below),
+  // so deeper levels run their full chains (correct, only slower on those off-design cloud sizes)
   else if (need > 1024 * 16 && need <= 1024 * 20 && variant == 4) GN_FPS_REGION(40);
-  else if (need > 1024 * 12 && need <= 1024 * 16 && variant == 3) GN_FPS_SPATIAL(16);
   else if (need > 1024 * 16 && need <= 1024 * 20 && variant == 3) GN_FPS_SPATIAL(20);
   else if (need <= 512 * 40 && variant == 1) GN_FPS_LAUNCH(512, 40);
   else if (need <= 256 * 80 && variant == 2) GN_FPS_LAUNCH(256, 80);

@@ -21,7 +21,7 @@ def _last_json(text):
 
 
 def test_bench_single_gpu_contract():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "12", "--cpu-scenes", "1"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "12", "--cpu-reps", "3"],
                          cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
@@ -32,8 +32,14 @@ def test_bench_single_gpu_contract():
     assert abs(d["value"] - 8 * 12 / (d["ms_per_step"] * 12e-3)) < 1e-6 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["avg_launch_ms"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0.05 < r["frac"] <= 1.0 and r["peak"] == 2500.0          # issued bf16 MFMA FLOP/s against the bf16 peak
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["cpu_model"]
+    # the legs beside the headline: single stream, the other cloud variant, the fp32-MFMA path, hipGraph latency
+    assert 0 < d["single_stream_scenes_per_s"] <= d["value"] * 1.05
+    assert d["surface_clouds"]["scenes_per_s"] > 250.0 and d["gn_math_f32_scenes_per_s"] > 250.0
+    assert set(d["hipgraph_latency_ms"]) == {"B=1", "B=8"} and d["hipgraph_latency_ms"]["B=1"] <= d["hipgraph_latency_ms"]["B=8"] * 1.05
+    assert {"ball_query_sa1", "group_points_sa2", "group_points_sa1", "cylinder_query"} <= set(d["op_rooflines"])
     assert "workload" in d["config"] and "model" not in d["config"]
 
 
@@ -48,3 +54,19 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     assert d["n_gpus"] == 2 and d["cpu_baseline"] is None and d["config"]["parallelism"] == "scene shards x2"
     assert abs(d["value"] - 2 * 8 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
     assert 16 * 300 < d["grasps_last_step"] < 16 * 1024          # every rank holds all 16 scenes' grasp lists
+    pr = d["per_rank_ms_per_step"]
+    assert len(pr["all"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - d["ms_per_step"]) < 1e-6 * d["ms_per_step"] + 1e-9
+
+
+def test_bench_strong_scaling_two_ranks_over_gloo():
+    """--global-batch: a fixed global batch of 16 cut into two contiguous shards of 8 (SURVEY.md 8e's strong-scaling run)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29519", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "6", "--warmup", "4", "--backend", "gloo", "--global-batch", "16"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["batch_per_gpu"] == 8
+    assert abs(d["value"] - 16 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
+    assert 16 * 300 < d["grasps_last_step"] < 16 * 1024

@@ -32,6 +32,8 @@ def _worker(rank, world, port, q):
             c[i] = scene + 1
             g[i, :scene + 1, 0] = float(scene)
         ga, ca = gdist.all_gather_grasps(g, c)
+        gb_, cb_, done = gdist.GraspGatherer().gather(g, c)       # CPU tensors: gathered inline, no event
+        assert done is None and torch.equal(gb_, ga) and torch.equal(cb_, ca)
         lst = gdist.to_list(ga, ca)
         ok = (ga.shape == (B_global, M, 17) and ca.tolist() == [s + 1 for s in range(B_global)]
               and all(t.shape == (s + 1, 17) and bool((t[:, 0] == s).all()) for s, t in enumerate(lst)))

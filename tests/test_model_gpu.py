@@ -325,7 +325,6 @@ def test_against_golden_samples(hip, golden_dir):
     ("config[1]: batch 8 x 20000-pt clouds", 8, 20000, "uniform", 1000),
     ("config[1] on surface clouds (duplicates, FPS ties)", 8, 20000, "surface", 1000),
     ("config[3]: dense 50000-pt cloud, full forward (B=1)", 1, 50000, "uniform", 1000),
-    ("config[3] on a surface cloud (B=1 x 50000)", 1, 50000, "surface", 1001),
 ])
 def test_baseline_configs_at_their_own_size(net, model_oracle, state_dict, name, B, N, variant, seed):
     """BASELINE.json's configurations at their own batch and cloud size on the HIP path, against the oracle (fp32 and

@@ -154,14 +154,17 @@ __device__ __forceinline__ int merge_low64(int a, int b, int lane) {
 
 constexpr int GQ_WAVES = 4;
 
-// ball query on the grid.  One wave per centre.  nsample <= 64.
+// ball query (CYL = false) or single-depth cylinder query (CYL = true: rot (B,M,9), hmin < x_rot < hmax, reach =
+// radius of the sphere containing the cylinder) on the grid.  One wave per centre.  nsample <= 64.
+template <bool CYL>
 __global__ __launch_bounds__(GQ_WAVES * 64) void ball_grid_kernel(const float *__restrict__ new_xyz,
+                                                                  const float *__restrict__ rot,
                                                                   const GridHeader *__restrict__ hdr,
                                                                   const int *__restrict__ cell_start,
                                                                   const float *__restrict__ sxyz,
                                                                   const int32_t *__restrict__ sidx, int n, int m,
-                                                                  float radius, int nsample,
-                                                                  int32_t *__restrict__ idx) {
+                                                                  float radius, float hmin, float hmax, float reach,
+                                                                  int nsample, int32_t *__restrict__ idx) {
   __shared__ int s_queue[GQ_WAVES][128];
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -174,13 +177,18 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void ball_grid_kernel(const float *_
   const float *c = new_xyz + ((size_t)b * m + j) * 3;
   int32_t *row = idx + ((size_t)b * m + j) * nsample;
   const float cx = c[0], cy = c[1], cz = c[2];
-  const float radius2 = radius * radius;   // ball_query_gpu.cu:27
+  const float radius2 = radius * radius;   // ball_query_gpu.cu:27, cylinder_query_gpu.cu:24
+  float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f, r4 = 0.f, r5 = 0.f, r6 = 0.f, r7 = 0.f, r8 = 0.f;
+  if (CYL) {
+    const float *r = rot + ((size_t)b * m + j) * 9;
+    r0 = r[0]; r1 = r[1]; r2 = r[2]; r3 = r[3]; r4 = r[4]; r5 = r[5]; r6 = r[6]; r7 = r[7]; r8 = r[8];
+  }
   // centre's cell from UNCLAMPED coordinates (a centre may lie outside the cloud's box)
   const int ccx = (int)floorf((cx - H.minx) * H.invx), ccy = (int)floorf((cy - H.miny) * H.invy),
             ccz = (int)floorf((cz - H.minz) * H.invz);
   // cell window: cells are at least 1.001 x the build reach wide; a grid built for a smaller reach just
   // widens the window
-  const int rx = (int)(radius * H.invx) + 1, ry = (int)(radius * H.invy) + 1, rz = (int)(radius * H.invz) + 1;
+  const int rx = (int)(reach * H.invx) + 1, ry = (int)(reach * H.invy) + 1, rz = (int)(reach * H.invz) + 1;
   const int x0 = max(ccx - rx, 0), x1 = min(ccx + rx, H.dx - 1);
   int *queue = s_queue[wv];
   int best = 0x7fffffff;    // ascending across lanes: the nsample... 64 smallest hit indices so far
@@ -197,9 +205,17 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void ball_grid_kernel(const float *_
           int k = 0;
           if (q < p1) {
             const float px = sxyz[q * 3 + 0], py = sxyz[q * 3 + 1], pz = sxyz[q * 3 + 2];
-            // ball_query_gpu.cu:33-38
-            const float d2 = (cx - px) * (cx - px) + (cy - py) * (cy - py) + (cz - pz) * (cz - pz);
-            hit = d2 < radius2;
+            if (CYL) {   // cylinder_query_gpu.cu:36-46
+              const float x = px - cx, y = py - cy, z = pz - cz;
+              const float x_rot = r0 * x + r3 * y + r6 * z;
+              const float y_rot = r1 * x + r4 * y + r7 * z;
+              const float z_rot = r2 * x + r5 * y + r8 * z;
+              const float d2 = y_rot * y_rot + z_rot * z_rot;
+              hit = d2 < radius2 && x_rot > hmin && x_rot < hmax;
+            } else {     // ball_query_gpu.cu:33-38
+              const float d2 = (cx - px) * (cx - px) + (cy - py) * (cy - py) + (cz - pz) * (cz - pz);
+              hit = d2 < radius2;
+            }
             k = sidx[q];
           }
           const unsigned long long mask = __ballot(hit);
@@ -411,9 +427,27 @@ extern "C" int gn_ball_query_grid(const float *new_xyz, const void *grid, int b,
   GridHeader *hdr; int *cs; float *sxyz; int32_t *sidx;
   grid_carve(const_cast<void *>(grid), b, n, &hdr, &cs, &sxyz, &sidx);
   dim3 g((m + GQ_WAVES - 1) / GQ_WAVES, b);
-  hipLaunchKernelGGL(ball_grid_kernel, g, dim3(GQ_WAVES * 64), 0, as_stream(stream), new_xyz, hdr, cs, sxyz, sidx, n, m,
-                     radius, nsample, idx);
+  hipLaunchKernelGGL(ball_grid_kernel<false>, g, dim3(GQ_WAVES * 64), 0, as_stream(stream), new_xyz, (const float *)nullptr,
+                     hdr, cs, sxyz, sidx, n, m, radius, 0.f, 0.f, radius, nsample, idx);
   GN_CHECK_LAUNCH("ball_query_grid");
+  return GN_OK;
+}
+
+extern "C" int gn_cylinder_query_grid(const float *new_xyz, const float *rot, const void *grid, int b, int n, int m,
+                                      float radius, float hmin, float hmax, int nsample, int32_t *idx, gn_stream_t stream) {
+  GN_REQUIRE(b >= 0 && n >= 1 && m >= 0 && nsample >= 1 && nsample <= 64, "cylinder_query_grid: bad sizes (nsample <= 64)");
+  if (b == 0 || m == 0) return GN_OK;
+  GN_REQUIRE(new_xyz && rot && grid && idx, "cylinder_query_grid: null pointer");
+  GN_REQUIRE(b <= 65535, "cylinder_query_grid: batch > 65535 unsupported");
+  GridHeader *hdr; int *cs; float *sxyz; int32_t *sidx;
+  grid_carve(const_cast<void *>(grid), b, n, &hdr, &cs, &sxyz, &sidx);
+  // every hit lies within this distance of the centre: radial < radius, axial in (hmin, hmax)
+  const float ax = fmaxf(fabsf(hmin), fabsf(hmax));
+  const float reach = sqrtf(radius * radius + ax * ax) * 1.0001f;
+  dim3 g((m + GQ_WAVES - 1) / GQ_WAVES, b);
+  hipLaunchKernelGGL(ball_grid_kernel<true>, g, dim3(GQ_WAVES * 64), 0, as_stream(stream), new_xyz, rot, hdr, cs, sxyz, sidx,
+                     n, m, radius, hmin, hmax, reach, nsample, idx);
+  GN_CHECK_LAUNCH("cylinder_query_grid");
   return GN_OK;
 }
 

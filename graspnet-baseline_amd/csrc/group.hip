@@ -7,9 +7,13 @@
 // element; here the (batch, channel, position) space is spread over the whole
 // chip with the OUTPUT index on the lane so stores are fully coalesced, and the
 // index row is read once per lane and reused for every channel.
+#include <stdlib.h>
+
 #include "gn_common.h"
 
 namespace gn {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 // out[b,c,j] = points[b,c,idx[b,j]]   (sampling_gpu.cu:13-25)
 __global__ __launch_bounds__(256) void gather_points_kernel(const float *__restrict__ points,
@@ -46,6 +50,58 @@ __global__ __launch_bounds__(256) void group_points_kernel(const float *__restri
   const int a = idx[(size_t)b * ne + e];
   for (int l = blockIdx.y; l < c; l += gridDim.y)
     out[((size_t)b * c + l) * ne + e] = points[((size_t)b * c + l) * n + a];
+}
+
+// The same gather for the write-bound shapes (group_points is named in BASELINE.json's metric): a workgroup stages CG
+// channel rows of one cloud in LDS (n floats each), then every thread takes 4 consecutive output elements at a time --
+// one 16-byte index load, 4 LDS gathers per channel, one 16-byte store per channel (1 KiB per wave-instruction instead
+// of 256 B, and no 4-byte global gathers).  grid = (element splits, channel groups, batch); ne % 4 == 0.
+template <int CG>
+__global__ __launch_bounds__(256) void group_points_lds_kernel(const float *__restrict__ points,
+                                                               const int32_t *__restrict__ idx, int c, int n, int ne,
+                                                               int quads_per_block, float *__restrict__ out) {
+  extern __shared__ float s_rows[];     // [CG][n]
+  const int b = blockIdx.z, c0 = blockIdx.y * CG, tid = threadIdx.x;
+  const int nc = min(CG, c - c0);
+  const float *src = points + ((size_t)b * c + c0) * n;      // nc consecutive rows = one contiguous block of nc*n floats
+  const int total = nc * n;
+  if ((n & 3) == 0) {
+    for (int i = tid * 4; i < total; i += 256 * 4) *reinterpret_cast<f32x4 *>(s_rows + i) = *reinterpret_cast<const f32x4 *>(src + i);
+  } else {
+    for (int i = tid; i < total; i += 256) s_rows[i] = src[i];
+  }
+  __syncthreads();
+  const int nq = ne >> 2;
+  const int q0 = blockIdx.x * quads_per_block, q1 = min(nq, q0 + quads_per_block);
+  using i32x4 = __attribute__((ext_vector_type(4))) int;
+  const i32x4 *iq = reinterpret_cast<const i32x4 *>(idx + (size_t)b * ne);
+  float *ob = out + ((size_t)b * c + c0) * ne;
+  for (int q = q0 + tid; q < q1; q += 256) {
+    const i32x4 a = iq[q];
+#pragma unroll 4
+    for (int l = 0; l < nc; ++l) {
+      const float *r = s_rows + l * n;
+      const f32x4 v{r[a[0]], r[a[1]], r[a[2]], r[a[3]]};
+      __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(ob + (size_t)l * ne) + q);
+    }
+  }
+}
+
+// rows too long for LDS (SA1 / CloudCrop: C = 3, n = N): 4 consecutive elements per thread straight from global,
+// 16-byte stores, two channels' gathers in flight.  ne % 4 == 0.
+__global__ __launch_bounds__(256) void group_points_vec_kernel(const float *__restrict__ points,
+                                                               const int32_t *__restrict__ idx, int c, int n, int ne,
+                                                               float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= (ne >> 2)) return;
+  using i32x4 = __attribute__((ext_vector_type(4))) int;
+  const i32x4 a = reinterpret_cast<const i32x4 *>(idx + (size_t)b * ne)[q];
+  for (int l = blockIdx.y; l < c; l += gridDim.y) {
+    const float *r = points + ((size_t)b * c + l) * n;
+    const f32x4 v{r[a[0]], r[a[1]], r[a[2]], r[a[3]]};
+    reinterpret_cast<f32x4 *>(out + ((size_t)b * c + l) * ne)[q] = v;
+  }
 }
 
 // group_points_gpu.cu:48-69
@@ -191,9 +247,49 @@ extern "C" int gn_group_points(const float *points, const int32_t *idx, int b, i
   if (b == 0 || c == 0 || ne == 0) return GN_OK;
   GN_REQUIRE(points && idx && out, "group_points: null pointer");
   GN_REQUIRE(ne < 0x7fffffffL, "group_points: npoints*nsample too large");
-  dim3 grid((unsigned)((ne + 255) / 256), chan_split(c), b);
-  hipLaunchKernelGGL(group_points_kernel, grid, dim3(256), 0, as_stream(stream), points, idx, c, n, (int)ne,
-                     out);
+  GN_REQUIRE(b <= 65535, "group_points: batch > 65535 unsupported");
+  const bool vec = (ne & 3) == 0 && (reinterpret_cast<uintptr_t>(idx) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(points) & 15) == 0;
+  if (vec && c >= 8 && (size_t)n * sizeof(float) * 2 <= 64 * 1024) {
+    // LDS-staged rows
+    static const int env_cg = []() { const char *e = getenv("GN_GROUP_CG"); return e ? atoi(e) : 0; }();
+    static const int env_wgs = []() { const char *e = getenv("GN_GROUP_WGS"); return e ? atoi(e) : 0; }();
+    // measured at the SA2 shape (profiles/group_probe.py): 2 rows per workgroup 5.3 TB/s, 4: 5.1-5.3, 8: 4.1-4.6, 16: 3.4-4.7
+    // (small LDS footprints keep many workgroups resident, so one's row staging hides under the others' stores)
+    int cg = (env_cg == 2 || env_cg == 4 || env_cg == 8 || env_cg == 16) ? env_cg : 2;
+    while ((size_t)cg * n * sizeof(float) > 64 * 1024) cg >>= 1;
+    const int gy = (c + cg - 1) / cg;
+    const int nq = (int)(ne >> 2);
+    const int want = env_wgs > 0 ? env_wgs : 1024;             // ~4 workgroups per CU in the grid
+    int split = 1;                                             // a power of two, so the element ranges stay even
+    while (split * b * gy < want) split <<= 1;
+    const int max_split = (nq + 511) / 512;                    // at least two quads per thread per workgroup
+    split = split < 1 ? 1 : (split > max_split ? max_split : split);
+    const int qpb = (nq + split - 1) / split;
+    const size_t lds = (size_t)cg * n * sizeof(float);
+    dim3 grid((unsigned)((nq + qpb - 1) / qpb), gy, b);
+    auto launch = [&](auto k) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        set_error("group_points: cannot reserve %zu bytes of LDS", lds);
+        return GN_ERR_LAUNCH;
+      }
+      hipLaunchKernelGGL(k, grid, dim3(256), lds, as_stream(stream), points, idx, c, n, (int)ne, qpb, out);
+      return GN_OK;
+    };
+    int rc;
+    if (cg == 16) rc = launch(group_points_lds_kernel<16>);
+    else if (cg == 8) rc = launch(group_points_lds_kernel<8>);
+    else if (cg == 4) rc = launch(group_points_lds_kernel<4>);
+    else rc = launch(group_points_lds_kernel<2>);
+    if (rc) return rc;
+  } else if (vec) {
+    dim3 grid((unsigned)(((ne >> 2) + 255) / 256), chan_split(c), b);
+    hipLaunchKernelGGL(group_points_vec_kernel, grid, dim3(256), 0, as_stream(stream), points, idx, c, n, (int)ne, out);
+  } else {
+    dim3 grid((unsigned)((ne + 255) / 256), chan_split(c), b);
+    hipLaunchKernelGGL(group_points_kernel, grid, dim3(256), 0, as_stream(stream), points, idx, c, n, (int)ne,
+                       out);
+  }
   GN_CHECK_LAUNCH("group_points");
   return GN_OK;
 }

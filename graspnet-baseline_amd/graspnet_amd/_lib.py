@@ -63,6 +63,8 @@ SIGNATURES = {
     "gn_grid_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
     "gn_grid_build": (_c_int, [_c_void_p, _c_int, _c_int, _c_float, _c_void_p, _c_void_p]),
     "gn_ball_query_grid": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_int, _c_void_p, _c_void_p]),
+    "gn_cylinder_query_grid": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float,
+                                        _c_int, _c_void_p, _c_void_p]),
     "gn_cylinder_query_unique_grid": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float,
                                                ctypes.POINTER(_c_float), _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "gn_cylinder_query_multi": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float,

@@ -36,6 +36,16 @@ def _cuda(t, name):
         raise RuntimeError("%s must be a CUDA tensor" % name)
 
 
+GRID_MIN_POINTS = 4096      # below this the index-order scan (query.hip) is as fast as binning the cloud first
+
+
+def _use_grid(n, m, nsample, radius):
+    """the grid kernels keep the nsample smallest hit indices in one 64-lane register: nsample <= 64"""
+    import os
+    return (n >= GRID_MIN_POINTS and m > 0 and 1 <= int(nsample) <= 64 and float(radius) > 0.0
+            and os.environ.get("GN_QUERY_PATH", "grid") != "brute")
+
+
 def _dispatch(first, others):
     """First tensor decides the device (e.g. ball_query.cpp:20-34)."""
     if not first.is_cuda:
@@ -92,8 +102,16 @@ def ball_query(new_xyz, xyz, radius, nsample):
     n = xyz.size(1)
     out = torch.empty((b, m, int(nsample)), dtype=torch.int32, device=new_xyz.device)
     with torch.cuda.device(new_xyz.device):
-        L.check(lib.gn_ball_query(new_xyz.data_ptr(), xyz.data_ptr(), b, n, m, float(radius), int(nsample),
-                                  out.data_ptr(), st), "ball_query")
+        if _use_grid(n, m, nsample, radius):
+            # the cloud binned once into cells >= radius, then only the cells a ball can touch are tested (same index
+            # lists as the scan: tests/test_ops_gpu.py); the grid workspace is a torch allocation like the output
+            grid = torch.empty((lib.gn_grid_workspace_bytes(b, n),), dtype=torch.uint8, device=new_xyz.device)
+            L.check(lib.gn_grid_build(xyz.data_ptr(), b, n, float(radius), grid.data_ptr(), st), "ball_query (grid build)")
+            L.check(lib.gn_ball_query_grid(new_xyz.data_ptr(), grid.data_ptr(), b, n, m, float(radius), int(nsample),
+                                           out.data_ptr(), st), "ball_query")
+        else:
+            L.check(lib.gn_ball_query(new_xyz.data_ptr(), xyz.data_ptr(), b, n, m, float(radius), int(nsample),
+                                      out.data_ptr(), st), "ball_query")
     return out
 
 
@@ -106,9 +124,16 @@ def cylinder_query(new_xyz, xyz, rot, radius, hmin, hmax, nsample):
     n = xyz.size(1)
     out = torch.empty((b, m, int(nsample)), dtype=torch.int32, device=new_xyz.device)
     with torch.cuda.device(new_xyz.device):
-        L.check(lib.gn_cylinder_query(new_xyz.data_ptr(), xyz.data_ptr(), rot.data_ptr(), b, n, m,
-                                      float(radius), float(hmin), float(hmax), int(nsample),
-                                      out.data_ptr(), st), "cylinder_query")
+        if _use_grid(n, m, nsample, radius):
+            reach = (float(radius) ** 2 + max(abs(float(hmin)), abs(float(hmax))) ** 2) ** 0.5
+            grid = torch.empty((lib.gn_grid_workspace_bytes(b, n),), dtype=torch.uint8, device=new_xyz.device)
+            L.check(lib.gn_grid_build(xyz.data_ptr(), b, n, reach, grid.data_ptr(), st), "cylinder_query (grid build)")
+            L.check(lib.gn_cylinder_query_grid(new_xyz.data_ptr(), rot.data_ptr(), grid.data_ptr(), b, n, m, float(radius),
+                                               float(hmin), float(hmax), int(nsample), out.data_ptr(), st), "cylinder_query")
+        else:
+            L.check(lib.gn_cylinder_query(new_xyz.data_ptr(), xyz.data_ptr(), rot.data_ptr(), b, n, m,
+                                          float(radius), float(hmin), float(hmax), int(nsample),
+                                          out.data_ptr(), st), "cylinder_query")
     return out
 
 

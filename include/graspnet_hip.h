@@ -140,6 +140,10 @@ size_t gn_grid_workspace_bytes(int b, int n);
 int gn_grid_build(const float *xyz, int b, int n, float reach, void *workspace, gn_stream_t stream);
 int gn_ball_query_grid(const float *new_xyz, const void *grid, int b, int n, int m, float radius, int nsample,
                        int32_t *idx, gn_stream_t stream);
+/* gn_cylinder_query (cylinder_query_gpu.cu:9-57, one depth) on the same grid: identical index lists; the cell window
+ * covers the sphere that contains the cylinder.  nsample <= 64. */
+int gn_cylinder_query_grid(const float *new_xyz, const float *rot, const void *grid, int b, int n, int m, float radius,
+                           float hmin, float hmax, int nsample, int32_t *idx, gn_stream_t stream);
 
 /* gn_cylinder_query_unique on the grid (any cell size; the kernel widens its cell window to the cylinder's
  * bounding sphere).  Same entries and masks; entries come grouped by minimum depth rather than in index

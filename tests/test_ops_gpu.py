@@ -124,9 +124,32 @@ def test_cylinder_query_bit_exact(E, oracle, model_oracle, n, m, hmax):
     assert torch.equal(got, want)
 
 
+def test_drop_in_queries_grid_equals_scan(E, model_oracle, monkeypatch):
+    """E.ball_query / E.cylinder_query bin the cloud for N >= 4096 (grid.hip); GN_QUERY_PATH=brute keeps the index-order
+    scan (query.hip): identical index lists, incl. centres far outside the cloud (zero rows) and nsample < 64"""
+    x = _cloud(77, 2, 9000, "surface")
+    c = x[:, ::9][:, :700].contiguous()
+    c[0, :5] += 3.0
+    rng = np.random.default_rng(9)
+    rot = model_oracle.viewpoint_to_matrix(torch.from_numpy(rng.standard_normal((2 * 700, 3)).astype(np.float32)),
+                                           torch.zeros(2 * 700)).view(2, 700, 9).contiguous()
+    xd, cd, rd = _dev(x), _dev(c), _dev(rot)
+    grid_b = [E.ball_query(cd, xd, r, ns) for r, ns in ((0.04, 64), (0.1, 32), (0.011, 7))]
+    grid_c = [E.cylinder_query(cd, xd, rd, 0.05, -0.02, h, ns) for h, ns in ((0.01, 64), (0.04, 64), (0.02, 10))]
+    monkeypatch.setenv("GN_QUERY_PATH", "brute")
+    scan_b = [E.ball_query(cd, xd, r, ns) for r, ns in ((0.04, 64), (0.1, 32), (0.011, 7))]
+    scan_c = [E.cylinder_query(cd, xd, rd, 0.05, -0.02, h, ns) for h, ns in ((0.01, 64), (0.04, 64), (0.02, 10))]
+    for a, b in zip(grid_b + grid_c, scan_b + scan_c):
+        assert torch.equal(a, b)
+    assert not grid_b[0][0, :5].any() and not grid_c[1][0, :5].any()
+
+
 def test_group_gather_bit_exact(E, oracle):
     g = torch.Generator().manual_seed(3)
-    for (b, c, n, npnt, ns) in [(2, 3, 20000, 2048, 64), (2, 128, 2048, 1024, 32), (1, 256, 512, 256, 16), (3, 5, 17, 3, 2)]:
+    # vectorised global gathers (C=3, long rows) / LDS-staged rows with 8, 16, 16 (odd n, partial last group) and 2 channels
+    # per workgroup / the scalar kernel (element count not a multiple of 4)
+    for (b, c, n, npnt, ns) in [(2, 3, 20000, 2048, 64), (2, 128, 2048, 1024, 32), (1, 256, 512, 256, 16), (2, 20, 1001, 50, 8),
+                                (1, 9, 8192, 64, 4), (3, 5, 17, 3, 2)]:
         f = torch.rand(b, c, n, generator=g)
         idx = torch.randint(0, n, (b, npnt, ns), generator=g, dtype=torch.int32)
         assert torch.equal(E.group_points(_dev(f), _dev(idx)).cpu(), oracle.group_points(f, idx))

@@ -122,16 +122,12 @@ __device__ __forceinline__ void load_fp_split(__bf16 *__restrict__ ys, int plane
 // One streamed layer, T orientation.  MFMA phase: every (M tile, n-tile) of this wave accumulates over all K with the
 // weight chunks double-buffered; then `retire()` (a workgroup barrier when the output overwrites the input) and the
 // epilogue epi(mt, nt, acc) per tile.
-template <int COUTP>
-struct StreamBias {      // this wave's accumulator-initial values (T orientation: 16 channel rows per n-tile), loaded once
-  static constexpr int NTW = (COUTP / 32) / wn_for(COUTP);
-  float v[NTW][16];
-  __device__ __forceinline__ void load(const float *__restrict__ bp, int wave, int lane) {
-    const int wn = wave % wn_for(COUTP);
+// bias of the 16 accumulator rows of n-tile nt (T orientation: rows = channels 8g + 4*(lane>>5) + j): four 16-byte loads,
+// issued when the layer starts and consumed by its epilogue, so their L2 round trip hides under the layer's MFMAs
+__device__ __forceinline__ void load_bias_t4(const float *__restrict__ bp, int nt, int lane, f32x4 (&bt)[4]) {
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) load_bias_t(bp, wn * NTW + i, lane, v[i]);
-  }
-};
+  for (int g = 0; g < 4; ++g) bt[g] = *reinterpret_cast<const f32x4 *>(bp + nt * 32 + 8 * g + 4 * (lane >> 5));
+}
 
 // shape of a streamed layer for this kernel family
 template <int TP, int CINP, int COUTP>
@@ -165,20 +161,32 @@ struct StreamChunk {
           v[i][kb][p] = *reinterpret_cast<const bf16x8 *>(
               wbase + ((((size_t)((wn * C::NTW + i) * C::KB + c * C::KBC + kb)) * 3 + p) * 64 + lane) * 16);
   }
+  // called where the chunk is consumed (its data is needed there anyway; at the load an asm operand would force the
+  // wait and undo the double buffering): from here on the fragments live in AGPRs and the MFMAs read them from there
+  // (mlp_split.h LayerWS::load), so the VGPRs stay free for the two accumulators per tile
+  __device__ __forceinline__ void pin() {
+#pragma unroll
+    for (int i = 0; i < C::NTW; ++i)
+#pragma unroll
+      for (int kb = 0; kb < C::KBC; ++kb)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) asm volatile("" : "+a"(v[i][kb][p]));
+  }
 };
 
 // (Requesting the NEXT layer's chunk 0 while this layer finishes -- each layer otherwise starts with an L2 round trip
 // for its first chunk, ~2.5 k cycles -- keeps three layers' chunk buffers live across the tile loop and spills
 // 250-850 bytes per lane as written; left for a restructured kernel.)
 template <int TP, int CINP, int COUTP, int XS, class Retire, class Epi>
-__device__ __forceinline__ void run_layer_stream_split_t(const void *__restrict__ wq, const StreamBias<COUTP> &bias,
+__device__ __forceinline__ void run_layer_stream_split_t(const void *__restrict__ wq, const float *__restrict__ bias,
                                                          const __bf16 *__restrict__ xs, int xplane, int wave, int lane,
                                                          Retire &&retire, Epi &&epi) {
   using C = StreamCfg<TP, CINP, COUTP>;
   constexpr int WN = C::WN, NTW = C::NTW, MTW = C::MTW, KBC = C::KBC, NCH = C::NCH;
   const int wm = wave / WN, wn = wave % WN;
-  asm volatile("" : "+s"(wq));   // keep this layer's own chunk loads below the barrier that precedes it
-  // two accumulators per tile (mlp_split.h mfma6_2acc): the large products round once per 16-k block, the small ones apart
+  asm volatile("" : "+s"(wq), "+s"(bias));   // keep this layer's own loads below the barrier that precedes it
+  // two accumulators per tile (mlp_split.h mfma6_2acc): the large products round once per 16-k block, the small ones
+  // apart; the bias joins them in the epilogue (the accumulators start from zero)
   f32x16 acc[MTW][NTW], accl[MTW][NTW];
 #pragma unroll
   for (int i = 0; i < NTW; ++i)
@@ -186,17 +194,21 @@ __device__ __forceinline__ void run_layer_stream_split_t(const void *__restrict_
     for (int mi = 0; mi < MTW; ++mi)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        acc[mi][i][r] = bias.v[i][r];
+        acc[mi][i][r] = 0.f;
         accl[mi][i][r] = 0.f;
       }
   StreamChunk<TP, CINP, COUTP> first, other;
   first.load(wq, 0, wave, lane);
+  f32x4 bt[NTW][4];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) load_bias_t4(bias, wn * NTW + i, lane, bt[i]);
 #pragma unroll 2
   for (int c = 0; c < NCH; ++c) {
     if (c + 1 < NCH) {
       if (c & 1) first.load(wq, c + 1, wave, lane); else other.load(wq, c + 1, wave, lane);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (c & 1) other.pin(); else first.pin();
 #pragma unroll
     for (int mi = 0; mi < MTW; ++mi) {
       const int mt = wm * MTW + mi;
@@ -221,7 +233,7 @@ __device__ __forceinline__ void run_layer_stream_split_t(const void *__restrict_
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][i][r] += accl[mi][i][r];
+      for (int r = 0; r < 16; ++r) acc[mi][i][r] = (acc[mi][i][r] + accl[mi][i][r]) + bt[i][r >> 2][r & 3];
       epi(wm * MTW + mi, wn * NTW + i, acc[mi][i]);
     }
 }
@@ -239,15 +251,6 @@ __global__ __launch_bounds__(MLP_THREADS) void point_mlp_split_kernel(PointSplit
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   auto barrier = []() { __syncthreads(); };
   auto none = []() {};
-  // biases in registers for the whole kernel: fetched per layer they put an L2 round trip in front of each layer's
-  // first MFMA (the accumulators start from them)
-  StreamBias<C1P> bias1;
-  StreamBias<(NL > 1 ? C2P : 128)> bias2;
-  StreamBias<(NL > 2 ? C3P : 128)> bias3;
-  bias1.load(a.b[0], wave, lane);
-  if constexpr (NL > 1) bias2.load(a.b[1], wave, lane);
-  if constexpr (NL > 2) bias3.load(a.b[2], wave, lane);
-
   GN_PROBE_INIT();
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     GN_PROBE(7);
@@ -281,20 +284,20 @@ __global__ __launch_bounds__(MLP_THREADS) void point_mlp_split_kernel(PointSplit
       }
     };
     if constexpr (NL == 1) {
-      run_layer_stream_split_t<TP, C0, C1P, XS>(a.w[0], bias1, buf, PL, wave, lane, none, to_global);
+      run_layer_stream_split_t<TP, C0, C1P, XS>(a.w[0], a.b[0], buf, PL, wave, lane, none, to_global);
     } else {
-      run_layer_stream_split_t<TP, C0, C1P, XS>(a.w[0], bias1, buf, PL, wave, lane, barrier, to_lds(C1L));
+      run_layer_stream_split_t<TP, C0, C1P, XS>(a.w[0], a.b[0], buf, PL, wave, lane, barrier, to_lds(C1L));
       GN_PROBE(2);
       __syncthreads();
       GN_PROBE(3);
       if constexpr (NL == 2) {
-        run_layer_stream_split_t<TP, C1L, C2P, XS>(a.w[1], bias2, buf, PL, wave, lane, none, to_global);
+        run_layer_stream_split_t<TP, C1L, C2P, XS>(a.w[1], a.b[1], buf, PL, wave, lane, none, to_global);
       } else {
-        run_layer_stream_split_t<TP, C1L, C2P, XS>(a.w[1], bias2, buf, PL, wave, lane, barrier, to_lds(C2L));
+        run_layer_stream_split_t<TP, C1L, C2P, XS>(a.w[1], a.b[1], buf, PL, wave, lane, barrier, to_lds(C2L));
         GN_PROBE(4);
         __syncthreads();
         GN_PROBE(5);
-        run_layer_stream_split_t<TP, C2L, C3P, XS>(a.w[2], bias3, buf, PL, wave, lane, none, to_global);
+        run_layer_stream_split_t<TP, C2L, C3P, XS>(a.w[2], a.b[2], buf, PL, wave, lane, none, to_global);
         GN_PROBE(6);
       }
     }

@@ -40,6 +40,13 @@ struct LayerWS {
   static constexpr int KB = CINP / 16;
   bf16x8 b[NTW][KB][3];
 
+  // PIN_AGPR: the resident fragments are only ever MFMA operands, and the MFMA reads A/B straight from AGPRs.  Left to
+  // itself hipcc keeps what does not fit the 256 VGPRs as AGPR *spill* copies and brings each fragment back with four
+  // v_accvgpr_read_b32 before every use (the CloudCrop kernel carried 1.3 of them per MFMA, on the VALU the epilogues
+  // compete for); an empty asm with an "a" constraint makes the AGPR the value's home, and the accumulators stay in VGPRs
+  // where the pooling / splitting epilogues read them without moves.  At most 256 AGPRs' worth may be pinned per wave.
+  // PIN_KB: k-blocks (from 0) whose fragments are pinned; KB pins the whole layer, 0 none.
+  template <bool PIN_AGPR = false, int PIN_KB = KB>
   __device__ __forceinline__ void load(const void *__restrict__ wp, int wave, int lane) {
     const int wn = wave % WN;
     const char *base = static_cast<const char *>(wp);
@@ -50,6 +57,15 @@ struct LayerWS {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
           b[i][kb][p] = *reinterpret_cast<const bf16x8 *>(base + ((((size_t)((wn * NTW + i) * KB + kb)) * 3 + p) * 64 + lane) * 16);
+    // pins only after every load has been issued: an asm operand must be in its register, i.e. each pin waits for its load
+    if constexpr (PIN_AGPR) {
+#pragma unroll
+      for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int kb = 0; kb < (PIN_KB < KB ? PIN_KB : KB); ++kb)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) asm volatile("" : "+a"(b[i][kb][p]));
+    }
   }
 };
 

@@ -50,8 +50,8 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_unique_split_kernel(const fl
   LayerWS<C2, C3> w3;
   using L2 = LayerWS<C1, C2>;
   using L3 = LayerWS<C2, C3>;
-  w2.load(W.w2, wave, lane);
-  w3.load(W.w3, wave, lane);
+  w2.template load<true>(W.w2, wave, lane);     // 48 + 192 = 240 AGPRs of resident weights
+  w3.template load<true>(W.w3, wave, lane);
   // Layer 1 (K = 3) on the vector ALUs, one (row, 8-channel) item per thread and M tile: 256 items per tile = exactly
   // one per thread, whatever the tile count (as 32x32 MFMA tiles it is 2 per M tile on 4 waves: 6 tiles on 4 waves in
   // the common 3-tile chunk, and the other two waves waited at the barrier).  The thread's 8 channels' weights come
@@ -326,8 +326,9 @@ __global__ __launch_bounds__(NWV * 64) void sa_hoist_split_kernel(const float *_
   L2 w2;
   L3 w3;
   w1.load(W.w1, W.b1, wave, lane);
-  w2.load(W.w2, wave, lane);
-  w3.load(W.w3, wave, lane);
+  // 96 + 192 registers of resident split weights: all of layer 3 and five of layer 2's eight k-blocks live in AGPRs (252)
+  w2.template load<true, 5>(W.w2, wave, lane);
+  w3.template load<true>(W.w3, wave, lane);
   float b2t[16], b3[L3::NTW];
   load_bias_t(W.b2, wave % L2::WN, lane, b2t);
 #pragma unroll

@@ -194,7 +194,9 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_unique_split_kernel(const fl
     GN_PROBE(7);
     __syncthreads();
     GN_PROBE(4);
-    if constexpr (PIPE & 2)
+    if constexpr ((PIPE & 6) == 6)
+      run_layer_split_n_pool_pipe2<TP, C2, C3, ND>(w3, b3, bufY2, P2, wave, lane, pool, mtc);
+    else if constexpr (PIPE & 2)
       run_layer_split_n_pool_pipe<TP, C2, C3, ND>(w3, b3, bufY2, P2, wave, lane, pool, mtc);
     else
       run_layer_split_n<TP, C2, C3>(w3, b3, bufY2, P2, wave, lane, pool, mtc);
@@ -525,7 +527,7 @@ extern "C" int gn_crop_unique_mlp_pool_split(const float *xyz, const float *seed
   if (spb_env > 0) spb = spb_env > kCropMaxSpb ? kCropMaxSpb : spb_env;   // the kernel's s_cnt[] holds kCropMaxSpb seeds
   constexpr int TP = 96;
   constexpr size_t lds = 2 * (3 * TP * sp_stride(128) + 3 * TP * sp_stride(64)) + sizeof(float) * (2 * TP * lds_stride(8) + 2 * TP * 4);
-  static const int pipe = []() { const char *e = getenv("GN_SPLIT_PIPE"); return e ? atoi(e) : 3; }();
+  static const int pipe = []() { const char *e = getenv("GN_SPLIT_PIPE"); return e ? atoi(e) : 7; }();
   int rc = GN_OK;
   auto launch = [&](auto k) {
     if ((rc = set_lds_attr(k, lds, "crop_unique_mlp_pool_split"))) return;
@@ -535,7 +537,8 @@ extern "C" int gn_crop_unique_mlp_pool_split(const float *xyz, const float *seed
   if (pipe == 0) launch(crop_unique_split_kernel<64, 128, 256, 4, 256, TP, 0>);
   else if (pipe == 1) launch(crop_unique_split_kernel<64, 128, 256, 4, 256, TP, 1>);
   else if (pipe == 2) launch(crop_unique_split_kernel<64, 128, 256, 4, 256, TP, 2>);
-  else launch(crop_unique_split_kernel<64, 128, 256, 4, 256, TP, 3>);
+  else if (pipe == 3) launch(crop_unique_split_kernel<64, 128, 256, 4, 256, TP, 3>);
+  else launch(crop_unique_split_kernel<64, 128, 256, 4, 256, TP, 7>);
   if (rc) return rc;
   GN_CHECK_LAUNCH("crop_unique_mlp_pool_split");
   return GN_OK;

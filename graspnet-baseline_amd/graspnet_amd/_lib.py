@@ -59,6 +59,12 @@ SIGNATURES = {
     "gn_three_nn": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "gn_three_interpolate": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
     "gn_three_interpolate_grad": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "gn_grad_workspace_bytes": (_c_size_t, [_c_int, _c_int, ctypes.c_long]),
+    "gn_gather_points_grad_det": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "gn_group_points_grad_det": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p,
+                                          _c_void_p]),
+    "gn_three_interpolate_grad_det": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p,
+                                               _c_void_p, _c_void_p]),
     "gn_knn": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "gn_grid_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
     "gn_grid_build": (_c_int, [_c_void_p, _c_int, _c_int, _c_float, _c_void_p, _c_void_p]),

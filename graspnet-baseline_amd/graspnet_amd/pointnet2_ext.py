@@ -46,6 +46,18 @@ def _use_grid(n, m, nsample, radius):
             and os.environ.get("GN_QUERY_PATH", "grid") != "brute")
 
 
+def _deterministic_grads():
+    """The gradient operators run as sorted-segment sums (csrc/grad_det.hip: bit-identical to a sequential loop, the same
+    every run) unless GN_GRAD=atomic asks for the reference's float atomicAdd scatter."""
+    import os
+    return os.environ.get("GN_GRAD", "deterministic") != "atomic"
+
+
+def _grad_ws(lib, b, ndest, entries, device):
+    nbytes = lib.gn_grad_workspace_bytes(b, ndest, entries)
+    return torch.empty((nbytes,), dtype=torch.uint8, device=device) if nbytes else None
+
+
 def _dispatch(first, others):
     """First tensor decides the device (e.g. ball_query.cpp:20-34)."""
     if not first.is_cuda:
@@ -89,8 +101,13 @@ def gather_points_grad(grad_out, idx, n):
     b, c, m = grad_out.shape
     out = torch.empty((b, c, int(n)), dtype=torch.float32, device=grad_out.device)
     with torch.cuda.device(grad_out.device):
-        L.check(lib.gn_gather_points_grad(grad_out.data_ptr(), idx.data_ptr(), b, c, int(n), m,
-                                          out.data_ptr(), st), "gather_points_grad")
+        if _deterministic_grads():
+            ws = _grad_ws(lib, b, int(n), m, grad_out.device)
+            L.check(lib.gn_gather_points_grad_det(grad_out.data_ptr(), idx.data_ptr(), b, c, int(n), m, L.ptr(ws),
+                                                  out.data_ptr(), st), "gather_points_grad")
+        else:
+            L.check(lib.gn_gather_points_grad(grad_out.data_ptr(), idx.data_ptr(), b, c, int(n), m,
+                                              out.data_ptr(), st), "gather_points_grad")
     return out
 
 
@@ -157,8 +174,13 @@ def group_points_grad(grad_out, idx, n):
     b, c, npoints, nsample = grad_out.shape
     out = torch.empty((b, c, int(n)), dtype=torch.float32, device=grad_out.device)
     with torch.cuda.device(grad_out.device):
-        L.check(lib.gn_group_points_grad(grad_out.data_ptr(), idx.data_ptr(), b, c, int(n), npoints, nsample,
-                                         out.data_ptr(), st), "group_points_grad")
+        if _deterministic_grads():
+            ws = _grad_ws(lib, b, int(n), npoints * nsample, grad_out.device)
+            L.check(lib.gn_group_points_grad_det(grad_out.data_ptr(), idx.data_ptr(), b, c, int(n), npoints, nsample, L.ptr(ws),
+                                                 out.data_ptr(), st), "group_points_grad")
+        else:
+            L.check(lib.gn_group_points_grad(grad_out.data_ptr(), idx.data_ptr(), b, c, int(n), npoints, nsample,
+                                             out.data_ptr(), st), "group_points_grad")
     return out
 
 
@@ -198,6 +220,11 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     b, c, n = grad_out.shape
     out = torch.empty((b, c, int(m)), dtype=torch.float32, device=grad_out.device)
     with torch.cuda.device(grad_out.device):
-        L.check(lib.gn_three_interpolate_grad(grad_out.data_ptr(), idx.data_ptr(), weight.data_ptr(), b, c, n,
-                                              int(m), out.data_ptr(), st), "three_interpolate_grad")
+        if _deterministic_grads():
+            ws = _grad_ws(lib, b, int(m), 3 * n, grad_out.device)
+            L.check(lib.gn_three_interpolate_grad_det(grad_out.data_ptr(), idx.data_ptr(), weight.data_ptr(), b, c, n, int(m),
+                                                      L.ptr(ws), out.data_ptr(), st), "three_interpolate_grad")
+        else:
+            L.check(lib.gn_three_interpolate_grad(grad_out.data_ptr(), idx.data_ptr(), weight.data_ptr(), b, c, n,
+                                                  int(m), out.data_ptr(), st), "three_interpolate_grad")
     return out

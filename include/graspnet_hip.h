@@ -111,6 +111,20 @@ int gn_three_interpolate(const float *points, const int32_t *idx, const float *w
 int gn_three_interpolate_grad(const float *grad_out, const int32_t *idx, const float *weight, int b,
                               int c, int n, int m, float *grad_points, gn_stream_t stream);
 
+/* DETERMINISTIC forms of the three gradient operators (csrc/grad_det.hip): the scatter-add of the reference
+ * (sampling_gpu.cu:39-62, group_points_gpu.cu:48-80, interpolate_gpu.cu:121-159 use float atomicAdd, whose result
+ * depends on retirement order) as a sorted-segment sum -- every destination adds its entries in ascending entry
+ * order, bit-identical to a sequential loop and identical from run to run.  Same arguments as the atomic forms
+ * above plus a workspace of gn_grad_workspace_bytes(b, destinations, entries per cloud) bytes
+ * (entries: m for gather, npoints*nsample for group, 3*n for three_interpolate whose destinations are m). */
+size_t gn_grad_workspace_bytes(int b, int n, long entries);
+int gn_gather_points_grad_det(const float *grad_out, const int32_t *idx, int b, int c, int n, int m, void *workspace,
+                              float *grad_points, gn_stream_t stream);
+int gn_group_points_grad_det(const float *grad_out, const int32_t *idx, int b, int c, int n, int npoints, int nsample,
+                             void *workspace, float *grad_points, gn_stream_t stream);
+int gn_three_interpolate_grad_det(const float *grad_out, const int32_t *idx, const float *weight, int b, int c, int n,
+                                  int m, void *workspace, float *grad_points, gn_stream_t stream);
+
 /* ------------------------------------------------------------------ *
  *  knn_pytorch.knn_pytorch.knn                                       *
  * ------------------------------------------------------------------ */

@@ -7,7 +7,9 @@ mkdir -p $HERE/probe/obj
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -I$ROOT/include -I$SRC -DGN_PHASE_PROBE"
 for f in $SRC/*.hip $SRC/*.cpp; do
   o=$HERE/probe/obj/$(basename $f).o
-  if [ ! -f $o ] || [ $f -nt $o ] || [ $SRC/mlp_core.h -nt $o ]; then /opt/rocm/bin/hipcc $FLAGS -x hip -c $f -o $o & fi
+  X=""
+  case $(basename $f) in mlp_split.hip|mlp_point_split.hip) X="-mllvm -amdgpu-mfma-vgpr-form";; esac   # as csrc/Makefile
+  if [ ! -f $o ] || [ $f -nt $o ] || [ $SRC/mlp_core.h -nt $o ] || [ $SRC/mlp_split.h -nt $o ]; then /opt/rocm/bin/hipcc $FLAGS $X -x hip -c $f -o $o & fi
 done
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $HERE/probe/libgraspnet_hip_probe.so $HERE/probe/obj/*.o

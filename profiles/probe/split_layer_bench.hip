@@ -21,7 +21,11 @@ __global__ __launch_bounds__(256) void bench(const void *wp, float *out, unsigne
   for (int i = tid; i < 3 * PL; i += 256) x[i] = (__bf16)((float)((i * 7) % 13) * 0.01f);
   for (int i = tid; i < TP * 4; i += 256) gate[i] = (i % 3) ? 0.f : -INFINITY;
   LayerWS<CIN, COUT> w;
+#ifdef BENCH_PIN
+  w.template load<true>(wp, wave, lane);
+#else
   w.load(wp, wave, lane);
+#endif
   __syncthreads();
   using LW = LayerWS<CIN, COUT>;
   float bias[LW::NTW] = {0.f, 0.f};
@@ -33,6 +37,7 @@ __global__ __launch_bounds__(256) void bench(const void *wp, float *out, unsigne
     if (MODE == 0) run_layer_split_n<TP, CIN, COUT>(w, bias, x, PL, wave, lane, ne, mtc);
     if (MODE == 1) run_layer_split_n<TP, CIN, COUT>(w, bias, x, PL, wave, lane, pool, mtc);
     if constexpr (MODE == 2) run_layer_split_n_pool_pipe<TP, CIN, COUT, 4>(w, bias, x, PL, wave, lane, pool, mtc);
+    if constexpr (MODE >= 3) run_layer_split_n_pool_pipe2<TP, CIN, COUT, 4, 4, MODE - 3>(w, bias, x, PL, wave, lane, pool, mtc);
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   float acc = ne.sink;
@@ -110,11 +115,15 @@ int main() {
   void *wp; float *out; unsigned long long *cyc;
   hipMalloc(&wp, 256 * 128 * 6); hipMalloc(&out, 4096 * 256 * 4); hipMalloc(&cyc, 4096 * 4 * 8);
   hipMemset(wp, 0, 256 * 128 * 6);
-  for (int blocks : {1})
+  for (int blocks : {1, 256})
     for (int mtc : {3, 2}) {
       run<0>("split N, bare", wp, out, cyc, blocks, mtc);
       run<1>("split N + masked pool", wp, out, cyc, blocks, mtc);
       run<2>("split N + pool, pipelined", wp, out, cyc, blocks, mtc);
+      run<3>("pipe2 (shared A frags)", wp, out, cyc, blocks, mtc);
+      run<4>("pipe2, no gate reads", wp, out, cyc, blocks, mtc);
+      run<5>("pipe2, gates, no pool math", wp, out, cyc, blocks, mtc);
+      run<6>("pipe2, neither", wp, out, cyc, blocks, mtc);
     }
   for (int mtc : {3, 2}) { run_t<0>("split T 64->128 + store", wp, out, cyc, mtc); run_t<1>("split T, pipelined", wp, out, cyc, mtc); }
   return 0;

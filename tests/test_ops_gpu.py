@@ -169,22 +169,36 @@ def test_three_nn_interpolate_bit_exact(E, oracle):
         assert torch.equal(E.three_interpolate(_dev(f), _dev(iw), _dev(w)).cpu(), oracle.three_interpolate(f, iw, w))
 
 
-def test_grad_ops(E, oracle):
+def test_grad_ops(E, oracle, monkeypatch):
+    """the three gradient operators as sorted-segment sums: BIT-IDENTICAL to the oracle's sequential ascending-entry loop
+    (and so identical from run to run), incl. destinations hit by hundreds of entries (wave rebuild path), by none, and
+    SA-sized shapes; GN_GRAD=atomic keeps the reference's float-atomic scatter (equal only to rounding)"""
     g = torch.Generator().manual_seed(5)
-    f_n, npnt, ns = 40, 12, 4
-    idx = torch.randint(0, f_n, (2, npnt, ns), generator=g, dtype=torch.int32)
-    go = torch.rand(2, 6, npnt, ns, generator=g)
-    torch.testing.assert_close(E.group_points_grad(_dev(go), _dev(idx), f_n).cpu(), oracle.group_points_grad(go, idx, f_n),
-                               rtol=1e-5, atol=1e-5)   # float atomics: sum order differs
-    gi = torch.randint(0, f_n, (2, npnt), generator=g, dtype=torch.int32)
-    go2 = torch.rand(2, 6, npnt, generator=g)
-    torch.testing.assert_close(E.gather_points_grad(_dev(go2), _dev(gi), f_n).cpu(), oracle.gather_points_grad(go2, gi, f_n),
-                               rtol=1e-5, atol=1e-5)
-    i3 = torch.randint(0, f_n, (2, 15, 3), generator=g, dtype=torch.int32)
-    w = torch.rand(2, 15, 3, generator=g)
-    go3 = torch.rand(2, 6, 15, generator=g)
-    torch.testing.assert_close(E.three_interpolate_grad(_dev(go3), _dev(i3), _dev(w), f_n).cpu(),
-                               oracle.three_interpolate_grad(go3, i3, w, f_n), rtol=1e-5, atol=1e-5)
+    for (b, c, f_n, npnt, ns, hot) in [(2, 6, 40, 12, 4, False), (2, 9, 2048, 1024, 32, False), (1, 3, 20000, 2048, 64, False),
+                                       (2, 5, 300, 64, 16, True)]:
+        idx = torch.randint(0, f_n, (b, npnt, ns), generator=g, dtype=torch.int32)
+        if hot:
+            idx[:, ::2, :8] = 7            # one destination collects 256 entries per cloud: > 64 -> the ordered wave rebuild
+        go = torch.rand(b, c, npnt, ns, generator=g)
+        want = oracle.group_points_grad(go, idx, f_n)
+        got = E.group_points_grad(_dev(go), _dev(idx), f_n)
+        assert torch.equal(got.cpu(), want)
+        assert torch.equal(E.group_points_grad(_dev(go), _dev(idx), f_n), got)          # run-to-run identical
+        gi = torch.randint(0, f_n, (b, npnt), generator=g, dtype=torch.int32)
+        if hot:
+            gi[:, :40] = 3
+        go2 = torch.rand(b, c, npnt, generator=g)
+        assert torch.equal(E.gather_points_grad(_dev(go2), _dev(gi), f_n).cpu(), oracle.gather_points_grad(go2, gi, f_n))
+        i3 = torch.randint(0, f_n, (b, npnt, 3), generator=g, dtype=torch.int32)
+        if hot:
+            i3[:, :, 0] = 5
+        w3 = torch.rand(b, npnt, 3, generator=g)
+        assert torch.equal(E.three_interpolate_grad(_dev(go2), _dev(i3), _dev(w3), f_n).cpu(),
+                           oracle.three_interpolate_grad(go2, i3, w3, f_n))
+    monkeypatch.setenv("GN_GRAD", "atomic")
+    torch.testing.assert_close(E.group_points_grad(_dev(go), _dev(idx), f_n).cpu(), want, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(E.three_interpolate_grad(_dev(go2), _dev(i3), _dev(w3), f_n).cpu(),
+                               oracle.three_interpolate_grad(go2, i3, w3, f_n), rtol=1e-5, atol=1e-4)
 
 
 def test_knn_bit_exact(oracle):

@@ -342,8 +342,21 @@ def main():
         uc = last_ep.get("_gn", {}).get("ucount")
         if rk in stages and N == 20000 and uc is not None:
             sec = stages[rk] * 1e-3
-            # MFMA work the kernel issues per launch: every unique (seed, point) row once, padded to 32-row tiles
-            rows = int((((uc + 31) // 32) * 32).sum().item())
+            # MFMA work the kernel issues per launch: every unique (seed, point) row once; the packed kernel (default,
+            # csrc/mlp_split.hip crop_packed_split_kernel) pads each WORKGROUP's row stream (spb consecutive seeds) to 32-row
+            # M tiles, GN_CROP_PACKED=0 / GN_MATH=f32 pad every seed
+            nseeds = int(uc.numel())
+            spb = max(1, min(16, nseeds // 512))
+            packed = net.math_split and os.environ.get("GN_CROP_PACKED", "1") != "0"
+            if packed:
+                flat = uc.reshape(-1).long()
+                pad = (-nseeds) % spb
+                if pad:
+                    flat = torch.cat([flat, flat.new_zeros(pad)])
+                rows = int((((flat.reshape(-1, spb).sum(1) + 31) // 32) * 32).sum().item())
+            else:
+                rows = int((((uc + 31) // 32) * 32).sum().item())
+            rows_unique = int(uc.sum().item())
             alg = FLOP_PER_SCENE["crop"] * B          # the reference's 4 x 64 rows per seed, fp32 MACs
             pmc_name, pmc = pmc_file()
             traffic = pmc.get(rk, {}) if (net.math_split and B == 8) else {}
@@ -353,9 +366,12 @@ def main():
                 issued, peak, unit_note = rows * CROP_FLOP_PER_ROW_F32, PEAK_F32_MFMA, "fp32 MFMA (v_mfma_f32_32x32x2_f32)"
             roof = {"bound": "mfma", "kernel": rk, "achieved": issued / sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
                     "frac": issued / sec / peak, "traffic": traffic.get("traffic_bytes"),
-                    "priced": "issued %s FLOP per launch = %d padded unique rows x %.0f, against that unit's dense peak"
-                              % (unit_note, rows, issued / rows),
+                    "priced": "issued %s FLOP per launch = %d evaluated rows (unique rows padded to 32-row tiles per %s) x %.0f, "
+                              "against that unit's dense peak; useful_frac counts the unique rows only"
+                              % (unit_note, rows, "workgroup stream" if packed else "seed", issued / rows),
                     "avg_launch_ms": stages[rk], "rows_per_seed": rows / float(uc.numel()),
+                    "rows_unique_per_seed": rows_unique / float(uc.numel()),
+                    "useful_frac": rows_unique * (issued / rows) / sec / peak,
                     "algorithmic": {"flop_per_launch": alg, "f32_equiv_tflops": alg / sec / 1e12,
                                     "x_f32_mfma_peak": alg / sec / PEAK_F32_MFMA,
                                     "note": "SURVEY.md 8d figure (21.576 GFLOP/scene: the reference evaluates 4 x 64 rows per seed as "

@@ -193,13 +193,17 @@ struct PoolMasked {
   }
   // out points at the seed's first depth row; depth rows are `ldo` floats apart
   __device__ __forceinline__ void finish(float *out, int ldo, int nt0) {
+    float v[ND][NTW];       // all cross-half maxima first, then ONE predicated block of stores (not a branch per value)
 #pragma unroll
     for (int d = 0; d < ND; ++d)
 #pragma unroll
-      for (int i = 0; i < NTW; ++i) {
-        const float v = xhalf_max(hold[d][i], lane);
-        if (lane < 32) out[(size_t)d * ldo + (nt0 + i) * 32 + lane] = fmaxf(v, 0.f);
-      }
+      for (int i = 0; i < NTW; ++i) v[d][i] = fmaxf(xhalf_max(hold[d][i], lane), 0.f);
+    if (lane < 32) {
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) out[(size_t)d * ldo + (nt0 + i) * 32 + lane] = v[d][i];
+    }
   }
 };
 

@@ -386,95 +386,140 @@ __device__ __forceinline__ void run_layer_split_n_pool_pipe(const LayerWS<CINP, 
   }
 }
 
-template <bool V>
-struct BoolTag { static constexpr bool value = V; };
+// ---- N orientation, unit = one M tile x ALL of this wave's n-tiles --------------------------------------------------
+// The M tile's activation fragments (3 KB per k-block) and its gates are read from LDS once and feed NTW x 6 MFMAs,
+// where the per-(M tile, n-tile) form above reads them once per n-tile (in this orientation every wave reads the whole
+// activation tile).  With POOLED, the masked pooling of the PREVIOUS M tile (accumulators `prev`, gates at `gprev`) rides
+// on this tile's 8 k-blocks: NTW x 8 slices of two accumulator rows each, gates read one k-block ahead.
+//   xr    : this lane's fragment base of the tile = xs + (mt*32 + (lane&31))*XS + 8*(lane>>5)
+//   gprev : this lane's gate base of the previous tile = sgate + (pmt*32 + 4*(lane>>5))*4
+// VAR (profiles/probe/split_layer_bench.hip only): 1 = no gate reads, 2 = gate reads but no pooling arithmetic.
+template <int ND, int NTW>
+__device__ __forceinline__ void pool_gate_read(f32x4 (&g)[2][2], const float *__restrict__ gbase, int j) {
+  const int r = 2 * j;
+  const int rb = (r & 3) + 8 * (r >> 2);
+  g[j & 1][0] = *reinterpret_cast<const f32x4 *>(gbase + rb * 4);
+  g[j & 1][1] = *reinterpret_cast<const f32x4 *>(gbase + (rb + 1) * 4);
+}
+template <int ND, int NTW>
+__device__ __forceinline__ void pool_slice(PoolMasked<ND, NTW> &pool, const f32x16 (&src)[NTW], const f32x4 (&g)[2][2], int j) {
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+      pool.hold[d][i] = fmaxf(pool.hold[d][i], fmaxf(src[i][2 * j] + g[j & 1][0][d], src[i][2 * j + 1] + g[j & 1][1][d]));
+}
+// the pooling of one M tile on its own (nothing to ride on): ALL its gates are requested before the first slice, so the
+// pass pays one LDS round trip instead of one per slice (it ran ~2x longer with the gates read a slice ahead)
+template <int ND, int NTW>
+__device__ __forceinline__ void pool_tile(PoolMasked<ND, NTW> &pool, const f32x16 (&src)[NTW], const float *__restrict__ gbase) {
+  f32x4 g[8][2];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int r = 2 * j;
+    const int rb = (r & 3) + 8 * (r >> 2);
+    g[j][0] = *reinterpret_cast<const f32x4 *>(gbase + rb * 4);
+    g[j][1] = *reinterpret_cast<const f32x4 *>(gbase + (rb + 1) * 4);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+        pool.hold[d][i] = fmaxf(pool.hold[d][i], fmaxf(src[i][2 * j] + g[j][0][d], src[i][2 * j + 1] + g[j][1][d]));
+}
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+// hook(kb) runs once per k-block between the MFMAs (independent VALU / LDS work riding along, e.g. the next chunk's layer 1)
+// NPOOL: 0 = MFMAs only; 1 = the previous tile `prev` is pooled with the gates at gprev into `pool` under them; 2 = it is
+// pooled twice, with gprev into `pool` and with gprevB into `poolB` (a tile holding rows of two pooling groups)
+template <int NPOOL, int CINP, int COUTP, int ND, int NWV = 4, int VAR = 0, class Hook = NoHook>
+__device__ __forceinline__ void split_n_unit(const LayerWS<CINP, COUTP, NWV> &w, const float (&bias)[LayerWS<CINP, COUTP, NWV>::NTW],
+                                             const __bf16 *__restrict__ xr, int xplane,
+                                             f32x16 (&dst)[LayerWS<CINP, COUTP, NWV>::NTW],
+                                             const f32x16 (&prev)[LayerWS<CINP, COUTP, NWV>::NTW],
+                                             PoolMasked<ND, LayerWS<CINP, COUTP, NWV>::NTW> &pool, const float *__restrict__ gprev,
+                                             PoolMasked<ND, LayerWS<CINP, COUTP, NWV>::NTW> &poolB, const float *__restrict__ gprevB,
+                                             Hook &&hook = Hook{}) {
+  using LW = LayerWS<CINP, COUTP, NWV>;
+  static_assert(LW::KB == 8, "8 pool slices ride on 8 k-blocks");
+  constexpr int KB = LW::KB, NTW = LW::NTW;
+  constexpr bool HOOKED = !__is_same(__remove_cvref(Hook), NoHook);
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[i][r] = bias[i];
+  bf16x8 a[KB][3];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) a[kb][p] = *reinterpret_cast<const bf16x8 *>(xr + p * xplane + kb * 16);
+  f32x4 g[2][2], gB[2][2];
+  auto gread = [&](int j) {
+    if constexpr (VAR & 1) g[j & 1][0] = g[j & 1][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    else pool_gate_read<ND, NTW>(g, gprev, j);
+    if constexpr (NPOOL > 1) pool_gate_read<ND, NTW>(gB, gprevB, j);
+  };
+  if constexpr (NPOOL > 0) gread(0);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    if (kb + 2 < KB) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[kb + 2][p] = *reinterpret_cast<const bf16x8 *>(xr + p * xplane + (kb + 2) * 16);
+    }
+    if constexpr (NPOOL > 0) { if (kb + 1 < 8) gread(kb + 1); }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) dst[i] = mfma6<false>(a[kb], w.b[i][kb], dst[i]);
+    if constexpr (NPOOL > 0) {
+      if constexpr (VAR & 2) pool.hold[0][0] = fmaxf(pool.hold[0][0], prev[0][2 * kb] + g[kb & 1][0][0] + g[kb & 1][1][3]);
+      else pool_slice<ND, NTW>(pool, prev, g, kb);
+      if constexpr (NPOOL > 1) pool_slice<ND, NTW>(poolB, prev, gB, kb);
+    }
+    hook(kb);
+    if constexpr (HOOKED || NPOOL > 1) {   // more riders per MFMA: ask for 4-5 VALU per gap and leave the LDS operations free
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) interleave_step<(NPOOL > 1 ? 5 : 4)>(5, 0);
+    } else {
+      __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) interleave_step<3>(5, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 
-// The same with unit = one M tile and ALL of this wave's n-tiles: the M tile's activation fragments (3 KB per k-block) and
-// its gates are read from LDS once and feed NTW x 6 MFMAs, where the per-(M tile, n-tile) form above reads them once per
-// n-tile.  That matters because in this orientation every wave reads the whole activation tile: with four waves the
-// CloudCrop layer 3 moved 320 KB through LDS per 32 rows against 128 B/clk (83 % of the time its 384 MFMAs need);
-// this form moves 160 KB.  Pooling of M tile t (NTW x 8 slices) rides on the 8 k-blocks of M tile t+1.
-// VAR (profiles/probe/split_layer_bench.hip only): 1 = no gate reads, 2 = gate reads but no pooling arithmetic, 3 = neither
+// A whole chunk of up to TP/32 M tiles of ONE pooling group: tile t's pooling under tile t+1's MFMAs, the last tile's on
+// its own (CloudCrop layer 3 moved 320 KB through LDS per 32 rows in the per-n-tile form, 160 KB in this one).
 template <int TP, int CINP, int COUTP, int ND, int NWV = 4, int VAR = 0>
 __device__ __forceinline__ void run_layer_split_n_pool_pipe2(const LayerWS<CINP, COUTP, NWV> &w,
                                                              const float (&bias)[LayerWS<CINP, COUTP, NWV>::NTW],
                                                              const __bf16 *__restrict__ xs, int xplane, int wave, int lane,
                                                              PoolMasked<ND, LayerWS<CINP, COUTP, NWV>::NTW> &pool, int mt_count) {
   using LW = LayerWS<CINP, COUTP, NWV>;
-  static_assert(LW::WM == 1 && LW::KB == 8, "every wave walks all M tiles; 8 pool slices ride on 8 k-blocks");
-  constexpr int XS = sp_stride(CINP), KB = LW::KB, NTW = LW::NTW, MAXU = TP / 32;
+  static_assert(LW::WM == 1, "every wave walks all M tiles");
+  constexpr int XS = sp_stride(CINP), NTW = LW::NTW, MAXU = TP / 32;
   static_assert(MAXU <= 4, "written out for up to four M tiles per chunk");
   if (mt_count == 0) return;
   f32x16 accA[NTW], accB[NTW];     // two named buffers (an array of buffers indexed by parity ends up in scratch)
   const __bf16 *xbase = xs + (lane & 31) * XS + 8 * (lane >> 5);
   const float *gbase = pool.sgate + (4 * (lane >> 5)) * 4;
-  f32x4 g[2][2];       // gates of slice j live in g[j & 1]: read one k-block ahead of their use
-  auto gate_read = [&](int mt, int j) {
-    if constexpr (VAR & 1) { g[j & 1][0] = g[j & 1][1] = f32x4{0.f, 0.f, 0.f, 0.f}; return; }
-    const int r = 2 * j;
-    const int rb = (r & 3) + 8 * (r >> 2);
-    g[j & 1][0] = *reinterpret_cast<const f32x4 *>(gbase + (mt * 32 + rb) * 4);
-    g[j & 1][1] = *reinterpret_cast<const f32x4 *>(gbase + (mt * 32 + rb + 1) * 4);
-  };
-  auto pool_slice = [&](const f32x16 (&src)[NTW], int j) {
-    if constexpr (VAR & 2) { pool.hold[0][0] = fmaxf(pool.hold[0][0], src[0][2 * j] + g[j & 1][0][0] + g[j & 1][1][3]); return; }
-#pragma unroll
-    for (int i = 0; i < NTW; ++i)
-#pragma unroll
-      for (int d = 0; d < ND; ++d)
-        pool.hold[d][i] = fmaxf(pool.hold[d][i], fmaxf(src[i][2 * j] + g[j & 1][0][d], src[i][2 * j + 1] + g[j & 1][1][d]));
-  };
-  // MFMAs of M tile mt into dst; with POOLED, the pooling of M tile mt-1 (held in prev) rides along
-  auto mma = [&](auto pooled, f32x16 (&dst)[NTW], int mt, const f32x16 (&prev)[NTW]) {
-    constexpr bool POOLED = decltype(pooled)::value;
-#pragma unroll
-    for (int i = 0; i < NTW; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dst[i][r] = bias[i];
-    const __bf16 *xr = xbase + mt * 32 * XS;
-    bf16x8 a[KB][3];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) a[kb][p] = *reinterpret_cast<const bf16x8 *>(xr + p * xplane + kb * 16);
-    if constexpr (POOLED) gate_read(mt - 1, 0);
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      if (kb + 2 < KB) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) a[kb + 2][p] = *reinterpret_cast<const bf16x8 *>(xr + p * xplane + (kb + 2) * 16);
-      }
-      if constexpr (POOLED) { if (kb + 1 < 8) gate_read(mt - 1, kb + 1); }
-#pragma unroll
-      for (int i = 0; i < NTW; ++i) dst[i] = mfma6<false>(a[kb], w.b[i][kb], dst[i]);
-      if constexpr (POOLED) pool_slice(prev, kb);
-      __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-#pragma unroll
-      for (int i = 0; i < NTW; ++i) interleave_step<3>(5, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  auto tail = [&](const f32x16 (&src)[NTW], int mt) {
-    gate_read(mt, 0);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (j + 1 < 8) gate_read(mt, j + 1);
-      pool_slice(src, j);
-    }
-  };
-  using Yes = BoolTag<true>;
-  using No = BoolTag<false>;
-  mma(No{}, accA, 0, accA);
+  auto xr = [&](int mt) { return xbase + mt * 32 * XS; };
+  auto gr = [&](int mt) { return gbase + mt * 32 * 4; };
+  split_n_unit<0, CINP, COUTP, ND, NWV, VAR>(w, bias, xr(0), xplane, accA, accA, pool, gbase, pool, gbase);
   if constexpr (MAXU > 1) {
-    if (1 < mt_count) mma(Yes{}, accB, 1, accA); else { tail(accA, 0); return; }
+    if (1 < mt_count) split_n_unit<1, CINP, COUTP, ND, NWV, VAR>(w, bias, xr(1), xplane, accB, accA, pool, gr(0), pool, gbase);
+    else { pool_tile<ND, NTW>(pool, accA, gr(0)); return; }
   }
   if constexpr (MAXU > 2) {
-    if (2 < mt_count) mma(Yes{}, accA, 2, accB); else { tail(accB, 1); return; }
+    if (2 < mt_count) split_n_unit<1, CINP, COUTP, ND, NWV, VAR>(w, bias, xr(2), xplane, accA, accB, pool, gr(1), pool, gbase);
+    else { pool_tile<ND, NTW>(pool, accB, gr(1)); return; }
   }
   if constexpr (MAXU > 3) {
-    if (3 < mt_count) mma(Yes{}, accB, 3, accA); else { tail(accA, 2); return; }
+    if (3 < mt_count) split_n_unit<1, CINP, COUTP, ND, NWV, VAR>(w, bias, xr(3), xplane, accB, accA, pool, gr(2), pool, gbase);
+    else { pool_tile<ND, NTW>(pool, accA, gr(2)); return; }
   }
-  if constexpr (((MAXU - 1) & 1) == 0) tail(accA, MAXU - 1); else tail(accB, MAXU - 1);
+  if constexpr (((MAXU - 1) & 1) == 0) pool_tile<ND, NTW>(pool, accA, gr(MAXU - 1));
+  else pool_tile<ND, NTW>(pool, accB, gr(MAXU - 1));
 }
 
 // ---- first layer (K = 3 coordinates, padded to 8) stays on the fp32 MFMA, T orientation, split epilogue -------

@@ -216,6 +216,335 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_unique_split_kernel(const fl
   GN_PROBE_FLUSH();
 }
 
+// ---- CloudCrop on PACKED rows (the default).  crop_unique_split_kernel above pads every seed's rows to whole 32-row M
+// tiles (85 unique rows per seed on the headline clouds -> 102.6 evaluated: 17 % of the MFMAs are padding) and starts a
+// new chunk at every seed (2.3 of the 3 M tiles a chunk can hold).  Here a workgroup's `spb` seeds form ONE row stream
+// -- seed after seed, no padding -- cut into full TP-row chunks.  A 32-row M tile may then hold rows of two (rarely more)
+// seeds: the staging threads write TWO gate tables per row, GA (the row's gates if it belongs to the tile's first seed,
+// else -inf) and GB (the same for the tile's second seed), so a tile is pooled with GA under the next tile's MFMAs
+// exactly like a one-seed tile, and a second seed costs one more pooling pass with GB; tiles with three or more seeds
+// (seeds with a handful of rows) take a generic path.  Layer 1 of chunk c+1 (vector ALUs) rides on the layer-3 MFMAs of
+// chunk c.  Every row goes through the same MFMAs in the same k order and max() is exact, so the result is bit-identical
+// to the padded kernel (tests/test_split_gpu.py).
+// RIDE: layer 1 of the next chunk under this chunk's layer-3 MFMAs (else on its own at the top of its chunk)
+template <int C1, int C2, int C3, int ND, int CAP, int TP, bool RIDE>
+__global__ __launch_bounds__(MLP_THREADS) void crop_packed_split_kernel(const float *__restrict__ xyz, int n,
+                                                                        const float *__restrict__ seed,
+                                                                        const float *__restrict__ rot,
+                                                                        const int32_t *__restrict__ uidx,
+                                                                        const int32_t *__restrict__ ucount, int m,
+                                                                        int nseeds, int spb, SplitWeights W,
+                                                                        float *__restrict__ out) {
+  constexpr int CIN0 = 8, XS0 = lds_stride(CIN0), MT = TP / 32;
+  static_assert(MT == 3, "the layer-3 walk below is written out for three M tiles per chunk");
+  constexpr int P2 = TP * sp_stride(C2), P1 = TP * sp_stride(C1);
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __bf16 *bufY2 = reinterpret_cast<__bf16 *>(smem_raw);            // 3 x [TP][C2+8]
+  __bf16 *bufY1 = bufY2 + 3 * P2;                                  // 3 x [TP][C1+8]
+  float *bufX = reinterpret_cast<float *>(bufY1 + 3 * P1);         // 2 x [TP+1][12]: rotated coordinates (+1 dump row)
+  float *bufGA = bufX + 2 * (TP + 1) * XS0;                        // 3 x [TP][4] gates towards the tile's first seed (chunk % 3)
+  float *bufGB = bufGA + 3 * TP * 4;                               // 3 x [TP][4] ... towards its second seed
+  int *bufS = reinterpret_cast<int *>(bufGB + 3 * TP * 4);         // 2 x [TP] seed slot | depth mask << 8 (-1: no row)
+  float *bufW1 = reinterpret_cast<float *>(bufS + 2 * TP);         // [C1][4] layer 1: w0 w1 w2 bias
+  __bf16 *dumpY1 = reinterpret_cast<__bf16 *>(bufW1 + C1 * 4);     // [8 x 8] bf16 x 3 planes: sink of an idle layer-1 slice
+  __shared__ int s_off[kCropMaxSpb + 1];                           // stream offset of each seed slot; [slots..] = total
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  using L2 = LayerWS<C1, C2>;
+  using L3 = LayerWS<C2, C3>;
+  static_assert(L3::WM == 1, "every wave walks all M tiles of layer 3");
+  static_assert(C1 == 64, "8 threads x 8 channels cover a row");
+  constexpr int NTW = L3::NTW;
+  L2 w2;
+  L3 w3;
+  w2.template load<true>(W.w2, wave, lane);
+  w3.template load<true>(W.w3, wave, lane);
+  if (tid < C1) {     // layer 1 (K = 3, on the vector ALUs) out of the fp32 fragment image: W1[c][k] = Wp[((c/32)*64 + c%32)*4 + k]
+    const float *wp = W.w1 + (size_t)(((tid >> 5) * 64 + (tid & 31)) * 4);
+    *reinterpret_cast<f32x4 *>(bufW1 + tid * 4) = f32x4{wp[0], wp[1], wp[2], W.b1[tid]};
+  }
+  float b2t[16], b3[NTW];
+  load_bias_t(W.b2, wave % L2::WN, lane, b2t);
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) b3[i] = W.b3[((wave % L3::WN) * NTW + i) * 32 + (lane & 31)];
+  PoolMasked<ND, NTW> pool{bufGA, lane, {}};
+  pool.reset();
+
+  const int s0 = blockIdx.x * spb;
+  const int nsd = min(nseeds, s0 + spb) - s0;       // seed slots of this workgroup (<= kCropMaxSpb)
+  if (nsd <= 0) return;
+  if (tid <= kCropMaxSpb) s_off[tid] = (tid >= 1 && tid <= nsd) ? ucount[s0 + tid - 1] : 0;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int k = 1; k <= kCropMaxSpb; ++k) { run += s_off[k]; s_off[k] = run; }    // slots past nsd repeat the total
+  }
+  __syncthreads();
+  const int R = s_off[nsd];                          // rows of the stream
+  const int nchunks = (R + TP - 1) / TP;
+  auto slot_of = [&](int p) {                        // seed slot of stream position p < R
+    int sl = 0;
+#pragma unroll
+    for (int k = 1; k < kCropMaxSpb; ++k) sl += (p >= s_off[k]) ? 1 : 0;
+    return sl;
+  };
+  // entry (and its seed slot) of this thread's row in chunk c; -1 = no row
+  auto load_e = [&](int c, int &slot) -> int {
+    const int p = c * TP + tid;
+    slot = 0;
+    if (tid >= TP || c >= nchunks || p >= R) return -1;
+    slot = slot_of(p);
+    return uidx[(size_t)(s0 + slot) * CAP + (p - s_off[slot])];
+  };
+  struct Raw { float px, py, pz, c0, c1, c2, r[9]; };
+  auto load_raw = [&](int e, int slot, Raw &w) {
+    if (e != -1) {
+      const int sf = s0 + slot;
+      const float *pp = xyz + ((size_t)(sf / m) * n + (e & 0x0fffffff)) * 3;
+      const float *cc = seed + (size_t)sf * 3;
+      const float *rr = rot + (size_t)sf * 9;
+      w.px = pp[0]; w.py = pp[1]; w.pz = pp[2];
+      w.c0 = cc[0]; w.c1 = cc[1]; w.c2 = cc[2];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) w.r[i] = rr[i];
+    }
+  };
+  // stage row `tid` of chunk c into buffer `buf`
+  auto put = [&](int buf, int c, int e, int slot, const Raw &w) {
+    if (tid >= TP) return;
+    const f32x4 ninf{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    f32x4 v{0.f, 0.f, 0.f, 0.f}, ga = ninf, gb = ninf;
+    int sv = -1;
+    if (e != -1) {
+      const unsigned mk = (unsigned)e >> 28;
+      const float x = w.px - w.c0, y = w.py - w.c1, z = w.pz - w.c2;
+      v[0] = x * w.r[0] + y * w.r[3] + z * w.r[6];   // (p-c)^T R, pointnet2_utils.py:528-530
+      v[1] = x * w.r[1] + y * w.r[4] + z * w.r[7];
+      v[2] = x * w.r[2] + y * w.r[5] + z * w.r[8];
+      f32x4 g;
+#pragma unroll
+      for (int d = 0; d < ND; ++d) g[d] = ((mk >> d) & 1u) ? 0.f : -INFINITY;
+      const int a_tile = slot_of(c * TP + (tid & ~31));      // seed of the tile's first row
+      if (slot == a_tile) ga = g;
+      if (slot == a_tile + 1) gb = g;
+      // slot | depth mask << 8 | (last row of its seed) << 16
+      sv = slot | (int)(mk << 8) | ((c * TP + tid + 1 == s_off[slot + 1]) ? 0x10000 : 0);
+    }
+    float *xo = bufX + buf * (TP + 1) * XS0 + tid * XS0;
+    *reinterpret_cast<f32x4 *>(xo) = v;
+    *reinterpret_cast<f32x4 *>(xo + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4 *>(bufGA + (c % 3) * TP * 4 + tid * 4) = ga;
+    *reinterpret_cast<f32x4 *>(bufGB + (c % 3) * TP * 4 + tid * 4) = gb;
+    bufS[buf * TP + tid] = sv;
+  };
+
+  // ---- layer 1 of one M tile, one (row, 8-channel) item per thread, cut into six slices so that it can ride on the k-blocks
+  // of a layer-3 unit (slice s at k-block s): 0 coordinates, 1-2 the 24 FMAs, 3-4 relu + split, 5 the three 16-byte stores
+  f32x4 l1x;
+  float l1y[8];
+  u32x2 l1h0, l1m0, l1l0, l1h1, l1m1, l1l1;
+  const float *l1w = bufW1 + (tid & 7) * 8 * 4;
+  auto l1_slice = [&](int sl, const float *xrow, __bf16 *dst, int plane) {
+    if (sl == 0) l1x = *reinterpret_cast<const f32x4 *>(xrow);
+    if (sl == 1 || sl == 2) {
+#pragma unroll
+      for (int j = 4 * (sl - 1); j < 4 * sl; ++j) {
+        const f32x4 wv = *reinterpret_cast<const f32x4 *>(l1w + j * 4);
+        l1y[j] = __builtin_fmaf(l1x[2], wv[2], __builtin_fmaf(l1x[1], wv[1], __builtin_fmaf(l1x[0], wv[0], wv[3])));
+      }
+    }
+    if (sl == 3) split4<true>(l1y[0], l1y[1], l1y[2], l1y[3], l1h0, l1m0, l1l0);
+    if (sl == 4) split4<true>(l1y[4], l1y[5], l1y[6], l1y[7], l1h1, l1m1, l1l1);
+    if (sl == 5) {
+      using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+      *reinterpret_cast<u32x4 *>(dst) = u32x4{l1h0[0], l1h0[1], l1h1[0], l1h1[1]};
+      *reinterpret_cast<u32x4 *>(dst + plane) = u32x4{l1m0[0], l1m0[1], l1m1[0], l1m1[1]};
+      *reinterpret_cast<u32x4 *>(dst + 2 * plane) = u32x4{l1l0[0], l1l0[1], l1l1[0], l1l1[1]};
+    }
+  };
+  // source row / destination of tile mt of the chunk staged in buffer b; inactive -> the dump row / sink (no branch)
+  auto l1_src = [&](int b, int mt, bool active) {
+    return bufX + b * (TP + 1) * XS0 + (active ? mt * 32 + (tid >> 3) : TP) * XS0;
+  };
+  auto l1_dst = [&](int mt, bool active) {
+    return active ? bufY1 + (mt * 32 + (tid >> 3)) * sp_stride(C1) + (tid & 7) * 8 : dumpY1 + (tid & 63) * 8;
+  };
+
+  int buf = 0, ent1, ent2 = -1, sl1 = 0, sl2 = 0;
+  {
+    int sl0;
+    const int e0 = load_e(0, sl0);
+    ent1 = load_e(1, sl1);
+    Raw w0{};
+    load_raw(e0, sl0, w0);
+    put(0, 0, e0, sl0, w0);
+    if (tid < XS0) bufX[TP * XS0 + tid] = bufX[(TP + 1) * XS0 + TP * XS0 + tid] = 0.f;     // the two dump rows
+  }
+  __syncthreads();
+  {   // layer 1 of the first chunk on its own
+    const int mtc0 = (min(TP, R) + 31) >> 5;
+    for (int mt = 0; mt < mtc0; ++mt)
+#pragma unroll
+      for (int sl = 0; sl < 6; ++sl) l1_slice(sl, l1_src(0, mt, true), l1_dst(mt, true), P1);
+  }
+  const int nt0 = (wave % L3::WN) * NTW;
+  GN_PROBE_INIT();
+  for (int c = 0; c < nchunks; ++c) {
+    const int rows = min(TP, R - c * TP);
+    const int mtc = (rows + 31) >> 5;
+    const bool has_next = c + 1 < nchunks;
+    const int mtc_next = has_next ? (min(TP, R - (c + 1) * TP) + 31) >> 5 : 0;
+    Raw w1{};
+    if (has_next) {
+      load_raw(ent1, sl1, w1);         // its entries were requested a whole chunk ago
+      ent2 = load_e(c + 2, sl2);       // entries of the chunk after next
+    }
+    // seeds of every tile of the chunk: the slot words of its first and last row, requested here so that the LDS round
+    // trip hides under layer 2 (consumed after it)
+    int rwa[MT], rwz[MT];
+    {
+      const int *sch_ = bufS + buf * TP;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        rwa[mt] = rwz[mt] = 0;
+        if (mt < mtc) {
+          rwa[mt] = sch_[mt * 32];
+          rwz[mt] = sch_[min(rows, mt * 32 + 32) - 1];
+        }
+      }
+    }
+    GN_PROBE(0);
+    if constexpr (!RIDE) {
+      if (c > 0)
+        for (int mt = 0; mt < mtc; ++mt)
+#pragma unroll
+          for (int sl = 0; sl < 6; ++sl) l1_slice(sl, l1_src(buf, mt, true), l1_dst(mt, true), P1);
+    }
+    GN_PROBE(1);
+    __syncthreads();                   // layer 1 of this chunk (done under the previous chunk's layer 3) is published
+    GN_PROBE(2);
+    StoreSplit e2{bufY2, sp_stride(C2), P2, lane};
+    run_layer_split_t_pipe<TP, C1, C2>(w2, b2t, bufY1, P1, wave, lane, e2, mtc);
+    GN_PROBE(3);
+    if (has_next) put(buf ^ 1, c + 1, ent1, sl1, w1);     // published by the barrier below
+    GN_PROBE(7);
+    __syncthreads();
+    GN_PROBE(4);
+
+    // ---- layer 3 + pooling, layer 1 of the next chunk riding along.  Tile t is pooled (gates GA: rows of its first seed)
+    // under the MFMAs of tile t+1; what cannot ride -- the chunk's last tile, a second seed's pass with GB -- is pooled on
+    // its own with all its gates fetched up front (carrying the last tile's accumulators across the next chunk's layer 2
+    // to let it ride too costs more registers than the kernel has: measured slower).
+    const float *gAc = bufGA + (c % 3) * TP * 4 + (4 * (lane >> 5)) * 4;
+    const float *gBc = bufGB + (c % 3) * TP * 4 + (4 * (lane >> 5)) * 4;
+    const int *sch = bufS + buf * TP;
+    const int p0 = c * TP;
+    const __bf16 *xbase = bufY2 + (lane & 31) * sp_stride(C2) + 8 * (lane >> 5);
+    auto xr = [&](int mt) { return xbase + mt * 32 * sp_stride(C2); };
+    // first / last seed of each tile, and whether the last one ends inside it (= the tile's last row is that seed's last)
+    int ta[MT], tz[MT];
+    bool tend[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int wa = __builtin_amdgcn_readfirstlane(rwa[mt]), wz = __builtin_amdgcn_readfirstlane(rwz[mt]);
+      ta[mt] = wa & 0xff;
+      tz[mt] = wz & 0xff;
+      tend[mt] = (wz & 0x10000) != 0;
+    }
+    auto finish_seed = [&](int q) {
+      GN_PROBE(5);
+      pool.finish(out + (size_t)(s0 + q) * ND * C3, C3, nt0);
+      pool.reset();
+      GN_PROBE(13);
+    };
+    // the pooling pass with GA of tile mt (seeds a..z, z <= a+1) has completed: close the tile
+    auto close_tile = [&](const f32x16 (&src)[NTW], int mt) {
+      if (tz[mt] == ta[mt]) {
+        if (tend[mt]) finish_seed(ta[mt]);
+      } else {            // the first seed ends inside the tile, the second gets its own pass
+        finish_seed(ta[mt]);
+        GN_PROBE(5);
+        pool_tile<ND, NTW>(pool, src, gBc + mt * 32 * 4);
+        GN_PROBE(12);
+        if (tend[mt]) finish_seed(tz[mt]);
+      }
+    };
+    // three or more seeds in one tile (seeds of a handful of rows): pooled on the spot, one pass per seed
+    auto pool_many = [&](const f32x16 (&src)[NTW], int mt) {
+      for (int q = ta[mt]; q <= tz[mt]; ++q) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int rw = mt * 32 + acc_row(2 * j, lane);
+          const int s0w = sch[rw], s1w = sch[rw + 1];
+          f32x4 g0, g1;
+#pragma unroll
+          for (int d = 0; d < ND; ++d) {
+            g0[d] = ((s0w & 0xff) == q && s0w >= 0 && ((s0w >> (8 + d)) & 1)) ? 0.f : -INFINITY;
+            g1[d] = ((s1w & 0xff) == q && s1w >= 0 && ((s1w >> (8 + d)) & 1)) ? 0.f : -INFINITY;
+          }
+#pragma unroll
+          for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+              pool.hold[d][i] = fmaxf(pool.hold[d][i], fmaxf(src[i][2 * j] + g0[d], src[i][2 * j + 1] + g1[d]));
+        }
+        if (q < tz[mt] || s_off[q + 1] <= p0 + mt * 32 + 32) finish_seed(q);
+      }
+    };
+    f32x16 accA[NTW], accB[NTW];
+    // one unit: MFMAs of tile MTI into DST; PEND: tile MTI-1 (in PRV) is pooled with GA under them; layer 1 of the next
+    // chunk's tile MTI rides along
+#define GN_CROP_UNIT(DST, PRV, MTI, PEND)                                                                                \
+    do {                                                                                                                 \
+      const bool l1a_ = (MTI) < mtc_next;                                                                                \
+      const float *l1s_ = l1_src(buf ^ 1, (MTI), l1a_);                                                                  \
+      __bf16 *l1d_ = l1_dst((MTI), l1a_);                                                                                \
+      auto hook_ = [&](int kb) { if (kb < 6) l1_slice(kb, l1s_, l1d_, l1a_ ? P1 : 64 * 8); };                            \
+      if constexpr (RIDE) {                                                                                              \
+        if (PEND) split_n_unit<1, C2, C3, ND>(w3, b3, xr(MTI), P2, DST, PRV, pool, gAc + ((MTI) - 1) * 32 * 4, pool, gAc, hook_); \
+        else split_n_unit<0, C2, C3, ND>(w3, b3, xr(MTI), P2, DST, DST, pool, gAc, pool, gAc, hook_);                     \
+      } else {                                                                                                           \
+        if (PEND) split_n_unit<1, C2, C3, ND>(w3, b3, xr(MTI), P2, DST, PRV, pool, gAc + ((MTI) - 1) * 32 * 4, pool, gAc); \
+        else split_n_unit<0, C2, C3, ND>(w3, b3, xr(MTI), P2, DST, DST, pool, gAc, pool, gAc);                            \
+      }                                                                                                                  \
+    } while (0)
+    GN_PROBE(14);
+    GN_CROP_UNIT(accA, accA, 0, false);
+    GN_PROBE(6);
+    bool pend = tz[0] <= ta[0] + 1;
+    if (!pend) pool_many(accA, 0);
+    if (mtc > 1) {
+      GN_PROBE(5);
+      if (pend) { GN_CROP_UNIT(accB, accA, 1, true); GN_PROBE(8); close_tile(accA, 0); }
+      else { GN_CROP_UNIT(accB, accB, 1, false); GN_PROBE(6); }
+      pend = tz[1] <= ta[1] + 1;
+      if (!pend) pool_many(accB, 1);
+      if (mtc > 2) {
+        GN_PROBE(5);
+        if (pend) { GN_CROP_UNIT(accA, accB, 2, true); GN_PROBE(8); close_tile(accB, 1); }
+        else { GN_CROP_UNIT(accA, accA, 2, false); GN_PROBE(6); }
+        if (tz[2] <= ta[2] + 1) { GN_PROBE(5); pool_tile<ND, NTW>(pool, accA, gAc + 2 * 32 * 4); GN_PROBE(12); close_tile(accA, 2); }
+        else pool_many(accA, 2);
+      } else if (pend) {
+        pool_tile<ND, NTW>(pool, accB, gAc + 1 * 32 * 4);
+        close_tile(accB, 1);
+      }
+    } else if (pend) {
+      pool_tile<ND, NTW>(pool, accA, gAc);
+      close_tile(accA, 0);
+    }
+#undef GN_CROP_UNIT
+    // a next chunk with more tiles than this one had units cannot occur (only the last chunk is short)
+    GN_PROBE(5);
+    GN_PROBE_COUNT(9, 1);
+    GN_PROBE_COUNT(10, mtc);
+    buf ^= 1;
+    ent1 = ent2;
+    sl1 = sl2;
+  }
+  GN_PROBE_FLUSH();
+}
+
 // ---- set abstraction, SA1 (no input features): SharedMLP[3,64,64,128] + max over 64 neighbours
 // (pointnet2_utils.py:344-355 + pointnet2_modules.py:251-257).  Layer 1 (K = 3) on the fp32 MFMA, layers 2-3 split.
 template <int C1, int C2, int C3, int NS, int TP, int MINW>
@@ -534,7 +863,21 @@ extern "C" int gn_crop_unique_mlp_pool_split(const float *xyz, const float *seed
     hipLaunchKernelGGL(k, dim3((nseeds + spb - 1) / spb), dim3(MLP_THREADS), lds, as_stream(stream), xyz, n, seed_xyz, rot,
                        uidx, ucount, m, nseeds, spb, W, out);
   };
-  if (pipe == 0) launch(crop_unique_split_kernel<64, 128, 256, 4, 256, TP, 0>);
+  const char *pe = getenv("GN_CROP_PACKED");      // read per call: tests A/B the two kernels in one process
+  const int packed = pe ? atoi(pe) : 1;
+  constexpr size_t lds_packed = 2 * (3 * TP * sp_stride(128) + 3 * TP * sp_stride(64)) +
+                                sizeof(float) * (2 * (TP + 1) * lds_stride(8) + 2 * 3 * TP * 4 + 2 * TP + 64 * 4) + 2 * 3 * 64 * 8;
+  if (packed) {
+    static const int ride = []() { const char *e = getenv("GN_CROP_RIDE"); return e ? atoi(e) : 1; }();
+    auto go = [&](auto k) {
+      if ((rc = set_lds_attr(k, lds_packed, "crop_unique_mlp_pool_split"))) return;
+      hipLaunchKernelGGL(k, dim3((nseeds + spb - 1) / spb), dim3(MLP_THREADS), lds_packed, as_stream(stream), xyz, n, seed_xyz,
+                         rot, uidx, ucount, m, nseeds, spb, W, out);
+    };
+    if (ride) go(crop_packed_split_kernel<64, 128, 256, 4, 256, TP, true>);
+    else go(crop_packed_split_kernel<64, 128, 256, 4, 256, TP, false>);
+    if (rc) return rc;
+  } else if (pipe == 0) launch(crop_unique_split_kernel<64, 128, 256, 4, 256, TP, 0>);
   else if (pipe == 1) launch(crop_unique_split_kernel<64, 128, 256, 4, 256, TP, 1>);
   else if (pipe == 2) launch(crop_unique_split_kernel<64, 128, 256, 4, 256, TP, 2>);
   else if (pipe == 3) launch(crop_unique_split_kernel<64, 128, 256, 4, 256, TP, 3>);

@@ -4,7 +4,7 @@
 set -e
 HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$(dirname "$HERE"); SRC=$ROOT/graspnet-baseline_amd/csrc
 mkdir -p $HERE/probe/obj
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -I$ROOT/include -I$SRC -DGN_PHASE_PROBE"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -I$ROOT/include -I$SRC -DGN_PHASE_PROBE $PROBE_DEFS"   # PROBE_DEFS: e.g. -DGN_DBG_NOPOOL
 for f in $SRC/*.hip $SRC/*.cpp; do
   o=$HERE/probe/obj/$(basename $f).o
   X=""

@@ -24,10 +24,11 @@ for _ in range(4):
 b.record(); torch.cuda.synchronize()
 print("crop kernel (instrumented): %.3f ms per launch" % (a.elapsed_time(b) / 4))
 lib.gn_phase_probe_read_split(buf, 1)
-names = ["fetch-issue", "L1", "bar1", "L2", "bar2", "L3+pool", "finish", "put", "bar3", "chunks", "mtiles"]
+names = ["fetch-issue", "L1", "bar1", "L2", "bar2", "L3 between units (close/finish/2nd pass/tail)", "L3 units without pool", "put", "L3 units with pool", "chunks", "mtiles", "mixed tiles"]
 for w in range(4):
     v = [buf[w * 16 + i] for i in range(16)]
     tot = sum(v[:9])
     print("wave %d: total %.3e  chunks %d mtiles %d | " % (w, tot, v[9], v[10]) + "  ".join("%s %.1f%%" % (names[i], 100.0 * v[i] / max(tot, 1)) for i in range(9)))
 v = [sum(buf[w * 16 + i] for w in range(4)) for i in range(16)]
-print("per M tile (avg over waves, probe clock ticks): " + "  ".join("%s %.0f" % (names[i], v[i] / max(v[10], 1)) for i in range(9)), " mtiles/chunk %.2f" % (v[10] / max(v[9], 1)))
+print("extra slots per M tile: standalone pool passes %.0f  finishes %.0f  classification %.0f" % (v[12] / max(v[10], 1), v[13] / max(v[10], 1), v[14] / max(v[10], 1)))
+print("per M tile (avg over waves, probe clock ticks): " + "  ".join("%s %.0f" % (names[i], v[i] / max(v[10], 1)) for i in range(9)), " mtiles/chunk %.2f  mixed tiles %.2f of tiles  total mtiles %d" % (v[10] / max(v[9], 1), v[11] / max(v[10], 1), v[10] / 4))

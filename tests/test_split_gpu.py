@@ -79,6 +79,52 @@ def test_crop_split_matches_float64_as_well_as_fp32(ref, truth, net):
     assert float((vsp - v32).abs().max()) <= 1e-4
 
 
+def test_crop_packed_rows_equal_padded_tiles(ref, net, monkeypatch):
+    """the packed-row CloudCrop kernel (a workgroup's seeds as one row stream, no per-seed padding, mixed tiles pooled once
+    per seed) == the per-seed padded kernel, bit for bit -- incl. seeds without neighbours (one zero-row entry each, so
+    several seeds share one 32-row tile) and a batch whose last workgroup is ragged"""
+    from graspnet_amd import _lib as L
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    B, N, M = 2, 20000, 1024
+    xyz = ref["input_xyz"].cuda()
+    seed = ref["fp2_xyz"].clone().cuda()
+    seed[0, 100:140] += 5.0              # 40 consecutive seeds far from the cloud: ucount 1 each
+    seed[1, 1000:] += 5.0                # ... and the tail of the second cloud
+    rot = ref["grasp_top_view_rot"].reshape(B, M, 9).contiguous().cuda()
+    uidx = torch.empty((B, M, 256), dtype=torch.int32, device="cuda")
+    ucount = torch.empty((B, M), dtype=torch.int32, device="cuda")
+    hmax = (ctypes.c_float * 4)(0.01, 0.02, 0.03, 0.04)
+    L.check(lib.gn_cylinder_query_unique(seed.data_ptr(), xyz.data_ptr(), rot.data_ptr(), B, N, M, 0.05, -0.02, hmax, 4, 64,
+                                         uidx.data_ptr(), ucount.data_ptr(), st), "cyl")
+    assert int(ucount[0, 100:140].max()) == 1
+    mlp = (ctypes.c_int * 3)(64, 128, 256)
+    pks = net._packed["crop_split"]
+    outs = {}
+    for mode, nseeds_b in (("1", B), ("0", B)):
+        monkeypatch.setenv("GN_CROP_PACKED", mode)
+        v = torch.full((B, M * 4, 256), float("nan"), device="cuda")
+        L.check(lib.gn_crop_unique_mlp_pool_split(xyz.data_ptr(), seed.data_ptr(), rot.data_ptr(), uidx.data_ptr(),
+                                                  ucount.data_ptr(), nseeds_b, N, M, 4, 64, mlp, pks.wptr, pks.bptr, v.data_ptr(), st),
+                "crop split packed=" + mode)
+        torch.cuda.synchronize()
+        outs[mode] = v
+    assert not torch.isnan(outs["1"]).any()
+    assert torch.equal(outs["1"], outs["0"])
+    # a ragged seed count (b*m not a multiple of the seeds per workgroup): m = 1000 seeds of cloud 0 only
+    res = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GN_CROP_PACKED", mode)
+        v = torch.full((1, 1000 * 4, 256), float("nan"), device="cuda")
+        L.check(lib.gn_crop_unique_mlp_pool_split(xyz.data_ptr(), seed.data_ptr(), rot.data_ptr(), uidx.data_ptr(),
+                                                  ucount.data_ptr(), 1, N, 1000, 4, 64, mlp, pks.wptr, pks.bptr, v.data_ptr(), st),
+                "crop split ragged packed=" + mode)
+        torch.cuda.synchronize()
+        res.append(v)
+    # (with m = 1000 the kernel reads seed / rot / uidx rows 0..999 of the same buffers: row stride is per seed)
+    assert not torch.isnan(res[0]).any() and torch.equal(res[0], res[1])
+
+
 def test_heads_and_approach_split_on_oracle_inputs(ref, truth, net):
     """per-point chains on the matrix-core path, fed with the ORACLE's inputs: within 1e-4 of the oracle's raw scores
     and as close to float64 as the fp32 kernels"""

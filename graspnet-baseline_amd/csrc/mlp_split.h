@@ -246,7 +246,8 @@ __device__ __forceinline__ void interleave_step(int nreads, int nwrites) {
 
 // T orientation, one n-tile per wave: split + store of this wave's M tile t under the MFMAs of its M tile t+1
 // (a quarter of the tile, 4 channels x this lane's position, behind every KB/4-th k-block)
-template <int TP, int CINP, int COUTP, int NWV = 4>
+// VAR (profiles/probe/split_layer_bench.hip only): 1 = no LDS stores, 2 = no split arithmetic (stores of raw bits)
+template <int TP, int CINP, int COUTP, int NWV = 4, int VAR = 0>
 __device__ __forceinline__ void run_layer_split_t_pipe(const LayerWS<CINP, COUTP, NWV> &w, const float (&bias_t)[16],
                                                        const __bf16 *__restrict__ xs, int xplane, int wave, int lane,
                                                        StoreSplit &epi, int mt_count = TP / 32) {
@@ -281,10 +282,20 @@ __device__ __forceinline__ void run_layer_split_t_pipe(const LayerWS<CINP, COUTP
   auto store_quarter = [&](const f32x16 &src, int mt, int g) {
     __bf16 *row = epi.ys + (mt * 32 + (lane & 31)) * epi.stride + wn * 32 + 4 * (lane >> 5) + 8 * g;
     u32x2 hi, mid, lo;
-    split4<true>(src[4 * g], src[4 * g + 1], src[4 * g + 2], src[4 * g + 3], hi, mid, lo);
-    *reinterpret_cast<u32x2 *>(row) = hi;
-    *reinterpret_cast<u32x2 *>(row + epi.plane) = mid;
-    *reinterpret_cast<u32x2 *>(row + 2 * epi.plane) = lo;
+    if constexpr (VAR & 2) {
+      hi = u32x2{__builtin_bit_cast(unsigned, src[4 * g]), __builtin_bit_cast(unsigned, src[4 * g + 1])};
+      mid = u32x2{__builtin_bit_cast(unsigned, src[4 * g + 2]), __builtin_bit_cast(unsigned, src[4 * g + 3])};
+      lo = hi;
+    } else {
+      split4<true>(src[4 * g], src[4 * g + 1], src[4 * g + 2], src[4 * g + 3], hi, mid, lo);
+    }
+    if constexpr (VAR & 1) {
+      if (hi[0] == 0x12345678u && mid[1] == 0x9abcdefu && lo[0] == 0x31415926u) *reinterpret_cast<u32x2 *>(row) = hi;   // keeps the values live
+    } else {
+      *reinterpret_cast<u32x2 *>(row) = hi;
+      *reinterpret_cast<u32x2 *>(row + epi.plane) = mid;
+      *reinterpret_cast<u32x2 *>(row + 2 * epi.plane) = lo;
+    }
   };
   mma(acc[0], wm, [](int) {});
 #pragma unroll

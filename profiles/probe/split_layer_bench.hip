@@ -80,7 +80,11 @@ __global__ __launch_bounds__(256) void bench_t(const void *wp, float *out, unsig
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < 3 * PL; i += 256) x[i] = (__bf16)((float)((i * 7) % 13) * 0.01f);
   LayerWS<CIN, COUT> w;
+#ifdef BENCH_PIN
+  w.template load<true>(wp, wave, lane);
+#else
   w.load(wp, wave, lane);
+#endif
   __syncthreads();
   float bt[16];
   for (int r = 0; r < 16; ++r) bt[r] = 0.01f * r;
@@ -89,6 +93,7 @@ __global__ __launch_bounds__(256) void bench_t(const void *wp, float *out, unsig
   for (int r = 0; r < reps; ++r) {
     if (MODE == 0) run_layer_split_t<TP, CIN, COUT>(w, bt, x, PL, wave, lane, e, mtc);
     if constexpr (MODE == 1) run_layer_split_t_pipe<TP, CIN, COUT>(w, bt, x, PL, wave, lane, e, mtc);
+    if constexpr (MODE >= 2) run_layer_split_t_pipe<TP, CIN, COUT, 4, MODE - 1>(w, bt, x, PL, wave, lane, e, mtc);
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   out[blockIdx.x * 256 + tid] = (float)y[tid];
@@ -115,7 +120,7 @@ int main() {
   void *wp; float *out; unsigned long long *cyc;
   hipMalloc(&wp, 256 * 128 * 6); hipMalloc(&out, 4096 * 256 * 4); hipMalloc(&cyc, 4096 * 4 * 8);
   hipMemset(wp, 0, 256 * 128 * 6);
-  for (int blocks : {1, 256})
+  for (int blocks : {256})
     for (int mtc : {3, 2}) {
       run<0>("split N, bare", wp, out, cyc, blocks, mtc);
       run<1>("split N + masked pool", wp, out, cyc, blocks, mtc);
@@ -125,6 +130,10 @@ int main() {
       run<5>("pipe2, gates, no pool math", wp, out, cyc, blocks, mtc);
       run<6>("pipe2, neither", wp, out, cyc, blocks, mtc);
     }
-  for (int mtc : {3, 2}) { run_t<0>("split T 64->128 + store", wp, out, cyc, mtc); run_t<1>("split T, pipelined", wp, out, cyc, mtc); }
+  for (int mtc : {3, 2}) {
+    run_t<0>("split T 64->128 + store", wp, out, cyc, mtc); run_t<1>("split T, pipelined", wp, out, cyc, mtc);
+    run_t<2>("T pipe, no LDS stores", wp, out, cyc, mtc); run_t<3>("T pipe, no split math", wp, out, cyc, mtc);
+    run_t<4>("T pipe, neither", wp, out, cyc, mtc);
+  }
   return 0;
 }

@@ -193,47 +193,7 @@ __device__ __forceinline__ void run_layer_split_t(const LayerWS<CINP, COUTP, NWV
   }
 }
 
-// ---- N orientation: acc[pos][cout] = X * W^T + b handed to a pooling epilogue (PoolMasked / PoolGlobal) -------
-template <int TP, int CINP, int COUTP, class Epi, int NWV = 4>
-__device__ __forceinline__ void run_layer_split_n(const LayerWS<CINP, COUTP, NWV> &w, const float (&bias)[LayerWS<CINP, COUTP, NWV>::NTW],
-                                                  const __bf16 *__restrict__ xs, int xplane, int wave, int lane, Epi &epi,
-                                                  int mt_count = TP / 32) {
-  using LW = LayerWS<CINP, COUTP, NWV>;
-  constexpr int XS = sp_stride(CINP), KB = LW::KB, NTW = LW::NTW;
-  const int wm = wave / LW::WN, wn = wave % LW::WN;
-  for (int mt = wm; mt < mt_count; mt += LW::WM) {
-    f32x16 acc[NTW];
-#pragma unroll
-    for (int i = 0; i < NTW; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = bias[i];
-    const __bf16 *xr = xs + (mt * 32 + (lane & 31)) * XS + 8 * (lane >> 5);
-    // operands two k-blocks ahead of their MFMAs; a sched_barrier per k-block keeps the window at three blocks
-    // (hipcc otherwise hoists all KB*3 fragment reads: 96 registers at K = 128)
-    bf16x8 a[KB][3];
-#pragma unroll
-    for (int kb = 0; kb < (KB < 2 ? KB : 2); ++kb)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) a[kb][p] = *reinterpret_cast<const bf16x8 *>(xr + p * xplane + kb * 16);
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      if (kb + 2 < KB) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) a[kb + 2][p] = *reinterpret_cast<const bf16x8 *>(xr + p * xplane + (kb + 2) * 16);
-      }
-#pragma unroll
-      for (int i = 0; i < NTW; ++i) acc[i] = mfma6<false>(a[kb], w.b[i][kb], acc[i]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) epi(mt, wn * NTW + i, i, acc[i]);
-  }
-}
-
-// ---- software-pipelined forms.  The bf16 MFMA runs on the matrix core and VALU / LDS instructions of the same wave
-// issue in its shadow (profiles/probe/mfma_bf16_overlap.hip: <= 4 fillers per MFMA are nearly free), so the epilogue of
-// output tile u is spread over the MFMAs of tile u+1.  The source is written step by step (one 16-k block = 6 MFMAs
-// per step) with a sched_barrier closing each step, and sched_group_barriers asking for 1 MFMA : NV VALU inside it.
+// one 16-k block of a software-pipelined layer: 6 x (1 MFMA, NV VALU) scheduling groups (see the pipelined forms below)
 template <int NV>
 __device__ __forceinline__ void interleave_step(int nreads, int nwrites) {
   (void)nreads; (void)nwrites;
@@ -243,6 +203,63 @@ __device__ __forceinline__ void interleave_step(int nreads, int nwrites) {
     __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
   }
 }
+
+struct NoHook2 { __device__ __forceinline__ void operator()(int, int) const {} };
+// one M tile: acc[pos][cout] of all of this wave's n-tiles, handed to the epilogue; hook(mt, kb) runs once per k-block
+// between the MFMAs (independent VALU / LDS work riding along)
+template <int CINP, int COUTP, class Epi, int NWV = 4, class Hook = NoHook2>
+__device__ __forceinline__ void split_n_tile(const LayerWS<CINP, COUTP, NWV> &w, const float (&bias)[LayerWS<CINP, COUTP, NWV>::NTW],
+                                             const __bf16 *__restrict__ xs, int xplane, int wave, int lane, Epi &epi, int mt,
+                                             Hook &&hook = Hook{}) {
+  using LW = LayerWS<CINP, COUTP, NWV>;
+  constexpr int XS = sp_stride(CINP), KB = LW::KB, NTW = LW::NTW;
+  const int wn = wave % LW::WN;
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = bias[i];
+  const __bf16 *xr = xs + (mt * 32 + (lane & 31)) * XS + 8 * (lane >> 5);
+  // operands two k-blocks ahead of their MFMAs; a sched_barrier per k-block keeps the window at three blocks
+  // (hipcc otherwise hoists all KB*3 fragment reads: 96 registers at K = 128)
+  bf16x8 a[KB][3];
+#pragma unroll
+  for (int kb = 0; kb < (KB < 2 ? KB : 2); ++kb)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) a[kb][p] = *reinterpret_cast<const bf16x8 *>(xr + p * xplane + kb * 16);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    if (kb + 2 < KB) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[kb + 2][p] = *reinterpret_cast<const bf16x8 *>(xr + p * xplane + (kb + 2) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) acc[i] = mfma6<false>(a[kb], w.b[i][kb], acc[i]);
+    hook(mt, kb);
+    if constexpr (!__is_same(__remove_cvref(Hook), NoHook2)) {
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) interleave_step<3>(0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) epi(mt, wn * NTW + i, i, acc[i]);
+}
+
+// ---- N orientation: acc[pos][cout] = X * W^T + b handed to a pooling epilogue (PoolMasked / PoolGlobal) -------
+template <int TP, int CINP, int COUTP, class Epi, int NWV = 4>
+__device__ __forceinline__ void run_layer_split_n(const LayerWS<CINP, COUTP, NWV> &w, const float (&bias)[LayerWS<CINP, COUTP, NWV>::NTW],
+                                                  const __bf16 *__restrict__ xs, int xplane, int wave, int lane, Epi &epi,
+                                                  int mt_count = TP / 32) {
+  using LW = LayerWS<CINP, COUTP, NWV>;
+  const int wm = wave / LW::WN;
+  for (int mt = wm; mt < mt_count; mt += LW::WM) split_n_tile<CINP, COUTP, Epi, NWV>(w, bias, xs, xplane, wave, lane, epi, mt);
+}
+
+// ---- software-pipelined forms.  The bf16 MFMA runs on the matrix core and VALU / LDS instructions of the same wave
+// issue in its shadow (profiles/probe/mfma_bf16_overlap.hip: <= 4 fillers per MFMA are nearly free), so the epilogue of
+// output tile u is spread over the MFMAs of tile u+1.  The source is written step by step (one 16-k block = 6 MFMAs
+// per step) with a sched_barrier closing each step, and sched_group_barriers asking for 1 MFMA : NV VALU inside it.
 
 // T orientation, one n-tile per wave: split + store of this wave's M tile t under the MFMAs of its M tile t+1
 // (a quarter of the tile, 4 channels x this lane's position, behind every KB/4-th k-block)

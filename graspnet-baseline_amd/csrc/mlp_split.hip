@@ -340,18 +340,21 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_packed_split_kernel(const fl
 
   // ---- layer 1 of one M tile, one (row, 8-channel) item per thread, cut into six slices so that it can ride on the k-blocks
   // of a layer-3 unit (slice s at k-block s): 0 coordinates, 1-2 the 24 FMAs, 3-4 relu + split, 5 the three 16-byte stores
-  f32x4 l1x;
+  // (every LDS read of a slice is consumed by a LATER slice: a wait inside a slice would stall the MFMAs behind it)
+  f32x4 l1x, l1wv[4];
   float l1y[8];
   u32x2 l1h0, l1m0, l1l0, l1h1, l1m1, l1l1;
   const float *l1w = bufW1 + (tid & 7) * 8 * 4;
   auto l1_slice = [&](int sl, const float *xrow, __bf16 *dst, int plane) {
-    if (sl == 0) l1x = *reinterpret_cast<const f32x4 *>(xrow);
     if (sl == 1 || sl == 2) {
 #pragma unroll
-      for (int j = 4 * (sl - 1); j < 4 * sl; ++j) {
-        const f32x4 wv = *reinterpret_cast<const f32x4 *>(l1w + j * 4);
-        l1y[j] = __builtin_fmaf(l1x[2], wv[2], __builtin_fmaf(l1x[1], wv[1], __builtin_fmaf(l1x[0], wv[0], wv[3])));
-      }
+      for (int j = 0; j < 4; ++j)
+        l1y[4 * (sl - 1) + j] = __builtin_fmaf(l1x[2], l1wv[j][2], __builtin_fmaf(l1x[1], l1wv[j][1], __builtin_fmaf(l1x[0], l1wv[j][0], l1wv[j][3])));
+    }
+    if (sl == 0) l1x = *reinterpret_cast<const f32x4 *>(xrow);
+    if (sl == 0 || sl == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) l1wv[j] = *reinterpret_cast<const f32x4 *>(l1w + (4 * sl + j) * 4);
     }
     if (sl == 3) split4<true>(l1y[0], l1y[1], l1y[2], l1y[3], l1h0, l1m0, l1l0);
     if (sl == 4) split4<true>(l1y[4], l1y[5], l1y[6], l1y[7], l1h1, l1m1, l1l1);
@@ -647,19 +650,21 @@ __global__ __launch_bounds__(NWV * 64) void sa_hoist_split_kernel(const float *_
   __bf16 *bufY1 = reinterpret_cast<__bf16 *>(smem_raw);     // 3 x [TP][C1+8]
   __bf16 *bufY2 = bufY1 + 3 * P1;                           // 3 x [TP][C2+8]
   float *bufX = reinterpret_cast<float *>(bufY2 + 3 * P2);  // 2 x [TP][12]
+  float *bufW1 = bufX + 2 * TP * XS0;                       // [C1][4]: layer 1's coordinate block w0 w1 w2 0
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  using L1 = LayerW<8, C1, NWV>;
   using L2 = LayerWS<C1, C2, NWV>;
   using L3 = LayerWS<C2, C3, NWV>;
-  static_assert(L1::WN == 4 && MT % L1::WM == 0, "layer 1: one n-tile per wave, M tiles divide over the wave rows");
-  constexpr int MTW = MT / L1::WM;
-  L1 w1;
+  static_assert(NWV == 4 && C1 == 128 && L3::WM == 1, "layer 1: one 32-channel n-tile per wave over all M tiles");
+  constexpr int MTW = MT;
   L2 w2;
   L3 w3;
-  w1.load(W.w1, W.b1, wave, lane);
   // 96 + 192 registers of resident split weights: all of layer 3 and five of layer 2's eight k-blocks live in AGPRs (252)
   w2.template load<true, 5>(W.w2, wave, lane);
   w3.template load<true>(W.w3, wave, lane);
+  if (tid < C1) {      // out of the fp32 fragment image: W1x[c][k] = Wp[((c/32)*64 + c%32)*4 + k], k < 3
+    const float *wp = W.w1 + (size_t)(((tid >> 5) * 64 + (tid & 31)) * 4);
+    *reinterpret_cast<f32x4 *>(bufW1 + tid * 4) = f32x4{wp[0], wp[1], wp[2], 0.f};
+  }
   float b2t[16], b3[L3::NTW];
   load_bias_t(W.b2, wave % L2::WN, lane, b2t);
 #pragma unroll
@@ -674,12 +679,12 @@ __global__ __launch_bounds__(NWV * 64) void sa_hoist_split_kernel(const float *_
   auto fetch_i = [&](int tl, int (&ix)[MTW], int &sx) {
     const int32_t *ixb = idx + (size_t)tl * GPT * NS;
 #pragma unroll
-    for (int mi = 0; mi < MTW; ++mi) ix[mi] = ixb[(wave / L1::WN + mi * L1::WM) * 32 + (lane & 31)];
+    for (int mi = 0; mi < MTW; ++mi) ix[mi] = ixb[mi * 32 + (lane & 31)];
     sx = tid < TP ? ixb[tid] : 0;
   };
   auto fetch_p = [&](int tl, const int (&ix)[MTW], f32x4 (&pf)[MTW][4]) {
     const int b = (tl * GPT) / np;
-    const float *pb = pfeat + (size_t)b * n * C1 + (wave % L1::WN) * 32 + 4 * (lane >> 5);
+    const float *pb = pfeat + (size_t)b * n * C1 + wave * 32 + 4 * (lane >> 5);
 #pragma unroll
     for (int mi = 0; mi < MTW; ++mi) {
       const float *row = pb + (size_t)ix[mi] * C1;
@@ -706,6 +711,35 @@ __global__ __launch_bounds__(NWV * 64) void sa_hoist_split_kernel(const float *_
       *reinterpret_cast<f32x4 *>(x + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
+  // ---- layer 1 on the vector ALUs (K = 3 on top of the gathered per-point rows), cut into 8 slices per M tile so that the
+  // NEXT tile's layer 1 rides on the k-blocks of this tile's layer 3: slices 0-3 the FMAs of channel quad g (weights from
+  // LDS), slices 4-7 relu + split + store of quad g.  acc rows of a lane: channels wave*32 + 8g + 4*(lane>>5) + j.
+  // (every LDS read of a slice is consumed by the NEXT slice: a wait inside a slice would stall the MFMAs behind it)
+  f32x4 l1x, l1wv[4];
+  float l1y[4][4];
+  const float *l1w = bufW1 + (wave * 32 + 4 * (lane >> 5)) * 4;
+  auto l1_slice = [&](int sl, int mi, const f32x4 (&pfr)[MTW][4], const float *xtile) {
+    if (sl >= 1 && sl <= 4) {         // FMAs of quad sl-1 with the weights requested by the previous slice
+      const int g = sl - 1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        l1y[g][j] = __builtin_fmaf(l1x[2], l1wv[j][2], __builtin_fmaf(l1x[1], l1wv[j][1], __builtin_fmaf(l1x[0], l1wv[j][0], pfr[mi][g][j])));
+    }
+    if (sl == 0) l1x = *reinterpret_cast<const f32x4 *>(xtile + (mi * 32 + (lane & 31)) * XS0);
+    if (sl < 4) {                     // weights of quad sl for the next slice
+#pragma unroll
+      for (int j = 0; j < 4; ++j) l1wv[j] = *reinterpret_cast<const f32x4 *>(l1w + (8 * sl + j) * 4);
+    }
+    if (sl >= 4) {                    // relu + split + store of quad sl-4
+      const int g = sl - 4;
+      u32x2 hi, mid, lo;
+      split4<true>(l1y[g][0], l1y[g][1], l1y[g][2], l1y[g][3], hi, mid, lo);
+      __bf16 *row = bufY1 + (mi * 32 + (lane & 31)) * sp_stride(C1) + wave * 32 + 4 * (lane >> 5) + 8 * g;
+      *reinterpret_cast<u32x2 *>(row) = hi;
+      *reinterpret_cast<u32x2 *>(row + P1) = mid;
+      *reinterpret_cast<u32x2 *>(row + 2 * P1) = lo;
+    }
+  };
 
   int buf = 0;
   f32x4 pf[MTW][4];
@@ -719,13 +753,16 @@ __global__ __launch_bounds__(NWV * 64) void sa_hoist_split_kernel(const float *_
     put_x(0, v);
   }
   __syncthreads();
+  // layer 1 of the first tile on its own; then the rows of the second tile are requested
+#pragma unroll
+  for (int mi = 0; mi < MTW; ++mi)
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) l1_slice(sl, mi, pf, bufX);
   GN_PROBE_INIT();
   for (; tile < tile_end; ++tile) {
     const int g0 = tile * GPT;
     const bool has_next = tile + 1 < tile_end;
     GN_PROBE(0);
-    StoreSplit e1{bufY1, sp_stride(C1), P1, lane};
-    run_layer_f32_t_cinit<TP, C1, MTW, NWV>(w1, pf, bufX + buf * TP * XS0, wave, lane, e1);
     f32x4 nv;
     if (has_next) {     // rows of the next tile (their indices arrived during the previous tile), then the indices after
       fetch_p(tile + 1, ixn, pf);
@@ -733,7 +770,7 @@ __global__ __launch_bounds__(NWV * 64) void sa_hoist_split_kernel(const float *_
       if (tile + 2 < tile_end) fetch_i(tile + 2, ixn, sxn);
     }
     GN_PROBE(1);
-    __syncthreads();
+    __syncthreads();                      // layer 1 of this tile (done under the previous tile's layer 3) is published
     GN_PROBE(2);
     StoreSplit e2{bufY2, sp_stride(C2), P2, lane};
     run_layer_split_t_pipe<TP, C1, C2, NWV>(w2, b2t, bufY1, P1, wave, lane, e2);
@@ -742,7 +779,14 @@ __global__ __launch_bounds__(NWV * 64) void sa_hoist_split_kernel(const float *_
     __syncthreads();
     GN_PROBE(4);
     PoolGlobal<NS, L3::NTW> e3{out + (size_t)g0 * C3, C3, lane, {}};
-    run_layer_split_n<TP, C2, C3, PoolGlobal<NS, L3::NTW>, NWV>(w3, b3, bufY2, P2, wave, lane, e3);
+    if (has_next) {
+      const float *xnext = bufX + (buf ^ 1) * TP * XS0;
+      auto hook = [&](int mt, int kb) { l1_slice(kb, mt, pf, xnext); };
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) split_n_tile<C2, C3, PoolGlobal<NS, L3::NTW>, NWV>(w3, b3, bufY2, P2, wave, lane, e3, mt, hook);
+    } else {
+      run_layer_split_n<TP, C2, C3, PoolGlobal<NS, L3::NTW>, NWV>(w3, b3, bufY2, P2, wave, lane, e3);
+    }
     GN_PROBE(5);
     GN_PROBE_COUNT(9, 1);
     GN_PROBE_COUNT(10, MT);
@@ -817,7 +861,7 @@ extern "C" int gn_sa_hoisted_mlp_pool_split(const float *xyz, const float *pfeat
   GN_REQUIRE(np % (TP / ns) == 0, "sa_hoisted_mlp_pool_split: npoint must be a multiple of %d", TP / ns);
   const SplitWeights W{static_cast<const float *>(wpacked[0]), bias[0], wpacked[1], wpacked[2], bias[1], bias[2]};
   const int ntiles = (int)((long)b * np / (TP / ns));
-  constexpr size_t lds = 2 * (3 * TP * sp_stride(128) + 3 * TP * sp_stride(128)) + sizeof(float) * (2 * TP * lds_stride(8));
+  constexpr size_t lds = 2 * (3 * TP * sp_stride(128) + 3 * TP * sp_stride(128)) + sizeof(float) * (2 * TP * lds_stride(8) + 128 * 4);
   const int tpb = split_tiles_per_block(ntiles);
   int rc;
   auto launch = [&](auto k, int threads) {

@@ -154,6 +154,28 @@ __device__ __forceinline__ int merge_low64(int a, int b, int lane) {
 
 constexpr int GQ_WAVES = 4;
 
+// Cell window [lo, hi] per axis that contains every point of the cylinder { p : hmin < a.(p-c) < hmax, |p-c - (a.(p-c))a| < radius }:
+// its axis-aligned bounding box is centre c + a(hmin+hmax)/2, half-extent |a_i|(hmax-hmin)/2 + radius*sqrt(1-a_i^2) per axis
+// (taken 0.2 % + 1e-6 wider: a is a float rotation column).  cell_coord is the monotone map the build kernel bins with, so a
+// point inside [lo_i, hi_i] lies in a cell inside [cell(lo_i), cell(hi_i)].  ~2.6x fewer candidate cells than the bounding
+// sphere's cube for CloudCrop's cylinders.
+struct CellWindow { int x0, x1, y0, y1, z0, z1; };
+__device__ __forceinline__ CellWindow cylinder_window(const GridHeader &H, float cx, float cy, float cz, float ax, float ay,
+                                                      float az, float radius, float hmin, float hmax) {
+  const float mid = 0.5f * (hmin + hmax), hl = 0.5f * (hmax - hmin);
+  auto span = [&](float c, float a, float mn, float inv, int dim, int &lo, int &hi) {
+    const float half = (fabsf(a) * hl + radius * sqrtf(fmaxf(0.f, 1.f - a * a))) * 1.002f + 1e-6f;
+    const float ctr = c + a * mid;
+    lo = cell_coord(ctr - half, mn, inv, dim);
+    hi = cell_coord(ctr + half, mn, inv, dim);
+  };
+  CellWindow w;
+  span(cx, ax, H.minx, H.invx, H.dx, w.x0, w.x1);
+  span(cy, ay, H.miny, H.invy, H.dy, w.y0, w.y1);
+  span(cz, az, H.minz, H.invz, H.dz, w.z0, w.z1);
+  return w;
+}
+
 // ball query (CYL = false) or single-depth cylinder query (CYL = true: rot (B,M,9), hmin < x_rot < hmax, reach =
 // radius of the sphere containing the cylinder) on the grid.  One wave per centre.  nsample <= 64.
 template <bool CYL>
@@ -189,14 +211,19 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void ball_grid_kernel(const float *_
   // cell window: cells are at least 1.001 x the build reach wide; a grid built for a smaller reach just
   // widens the window
   const int rx = (int)(reach * H.invx) + 1, ry = (int)(reach * H.invy) + 1, rz = (int)(reach * H.invz) + 1;
-  const int x0 = max(ccx - rx, 0), x1 = min(ccx + rx, H.dx - 1);
+  int x0 = max(ccx - rx, 0), x1 = min(ccx + rx, H.dx - 1);
+  int y0 = max(ccy - ry, 0), y1 = min(ccy + ry, H.dy - 1), z0 = max(ccz - rz, 0), z1 = min(ccz + rz, H.dz - 1);
+  if (CYL) {      // the oriented cylinder's own bounding box instead of its bounding sphere's cube
+    const CellWindow w = cylinder_window(H, cx, cy, cz, r0, r3, r6, radius, hmin, hmax);
+    x0 = max(x0, w.x0); x1 = min(x1, w.x1); y0 = max(y0, w.y0); y1 = min(y1, w.y1); z0 = max(z0, w.z0); z1 = min(z1, w.z1);
+  }
   int *queue = s_queue[wv];
   int best = 0x7fffffff;    // ascending across lanes: the nsample... 64 smallest hit indices so far
   int qn = 0;               // hits waiting in the queue
   int total = 0;
   if (x0 <= x1) {
-    for (int zz = max(ccz - rz, 0); zz <= min(ccz + rz, H.dz - 1); ++zz)
-      for (int yy = max(ccy - ry, 0); yy <= min(ccy + ry, H.dy - 1); ++yy) {
+    for (int zz = z0; zz <= z1; ++zz)
+      for (int yy = y0; yy <= y1; ++yy) {
         const int cb = (zz * H.dy + yy) * H.dx;
         const int p0 = cell_start[cb + x0], p1 = cell_start[cb + x1 + 1];
         for (int p = p0; p < p1; p += 64) {
@@ -287,7 +314,11 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void cylinder_unique_grid_kernel(
   const int ccx = (int)floorf((cx - H.minx) * H.invx), ccy = (int)floorf((cy - H.miny) * H.invy),
             ccz = (int)floorf((cz - H.minz) * H.invz);
   const int rx = (int)(reach * H.invx) + 1, ry = (int)(reach * H.invy) + 1, rz = (int)(reach * H.invz) + 1;
-  const int x0 = max(ccx - rx, 0), x1 = min(ccx + rx, H.dx - 1);
+  // the bounding sphere's cube, cut down to the bounding box of the deepest (= largest) of the nested cylinders
+  const CellWindow cw = cylinder_window(H, cx, cy, cz, r0, r3, r6, radius, hmin, hmax[ND - 1]);
+  const int x0 = max(max(ccx - rx, 0), cw.x0), x1 = min(min(ccx + rx, H.dx - 1), cw.x1);
+  const int y0 = max(max(ccy - ry, 0), cw.y0), y1 = min(min(ccy + ry, H.dy - 1), cw.y1);
+  const int z0 = max(max(ccz - rz, 0), cw.z0), z1 = min(min(ccz + rz, H.dz - 1), cw.z1);
   int best[ND], qn[ND], total[ND];
 #pragma unroll
   for (int d = 0; d < ND; ++d) { best[d] = 0x7fffffff; qn[d] = 0; total[d] = 0; }
@@ -304,8 +335,8 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void cylinder_unique_grid_kernel(
   };
 
   if (x0 <= x1) {
-    for (int zz = max(ccz - rz, 0); zz <= min(ccz + rz, H.dz - 1); ++zz)
-      for (int yy = max(ccy - ry, 0); yy <= min(ccy + ry, H.dy - 1); ++yy) {
+    for (int zz = z0; zz <= z1; ++zz)
+      for (int yy = y0; yy <= y1; ++yy) {
         const int cb = (zz * H.dy + yy) * H.dx;
         const int p0 = cell_start[cb + x0], p1 = cell_start[cb + x1 + 1];
         for (int p = p0; p < p1; p += 64) {

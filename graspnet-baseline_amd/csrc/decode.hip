@@ -49,7 +49,7 @@ __global__ __launch_bounds__(1024) void pred_decode_kernel(const float *__restri
                                                            const int64_t *__restrict__ top_inds,
                                                            const float *__restrict__ seed_xyz,
                                                            const float *__restrict__ rot_table, int m, int nd,
-                                                           int na, float *__restrict__ grasps,
+                                                           int na, int vec16, float *__restrict__ grasps,
                                                            int32_t *__restrict__ counts) {
   __shared__ int s_wave[16];
   __shared__ int s_base;
@@ -71,6 +71,32 @@ __global__ __launch_bounds__(1024) void pred_decode_kernel(const float *__restri
     if (s < m) {
       const float *f = feat + (size_t)s * ldf;
       keep = f[1] > f[0];  // argmax(objectness,0)==1  (graspnet.py:112-113)
+      if (na == 12 && vec16) {
+        // the reference configuration: a (seed, depth) row is 48 floats = 12 x 16-byte loads, all requested before the
+        // first compare (the scalar walk below chains ~50 dependent 4-byte loads per depth and made this kernel 45 us)
+        using f32x4 = __attribute__((ext_vector_type(4))) float;
+        for (int d = 0; d < nd; ++d) {
+          const f32x4 *h4 = reinterpret_cast<const f32x4 *>(head + ((size_t)s * nd + d) * hc);
+          f32x4 q[12];
+#pragma unroll
+          for (int i = 0; i < 12; ++i) q[i] = h4[i];
+          int a = 0;
+          float av = q[3][0];
+#pragma unroll
+          for (int t = 1; t < 12; ++t) {  // graspnet.py:93 angle class per (seed, depth): first maximum
+            const float v = q[3 + (t >> 2)][t & 3];
+            if (v > av) { av = v; a = t; }
+          }
+          float sc = 0.f, wd = 0.f, tl = 0.f;
+#pragma unroll
+          for (int t = 0; t < 12; ++t) {
+            if (t == a) { sc = q[t >> 2][t & 3]; wd = q[6 + (t >> 2)][t & 3]; tl = q[9 + (t >> 2)][t & 3]; }
+          }
+          if (d == 0 || sc > score) {  // graspnet.py:103 depth class = argmax of the gathered score
+            score = sc; bd = d; ba = a; width = wd; tol = tl;
+          }
+        }
+      } else {
       for (int d = 0; d < nd; ++d) {
         const float *h = head + ((size_t)s * nd + d) * hc;
         int a = 0;
@@ -85,6 +111,7 @@ __global__ __launch_bounds__(1024) void pred_decode_kernel(const float *__restri
           width = h[2 * na + a];
           tol = h[3 * na + a];
         }
+      }
       }
     }
     const unsigned long long mask = __ballot(keep);
@@ -144,8 +171,9 @@ extern "C" int gn_pred_decode(const float *feat, int ldf, const float *head, con
   GN_REQUIRE(b >= 0 && m >= 0 && ndepth >= 1 && nangle >= 1 && ldf >= 2, "pred_decode: bad sizes");
   if (b == 0) return GN_OK;
   GN_REQUIRE(feat && head && top_inds && seed_xyz && rot_table && grasps && counts, "pred_decode: null pointer");
+  const int vec16 = (reinterpret_cast<uintptr_t>(head) & 15) == 0 ? 1 : 0;     // 16-byte row loads need an aligned tensor
   hipLaunchKernelGGL(pred_decode_kernel, dim3(b), dim3(1024), 0, as_stream(stream), feat, ldf, head, top_inds,
-                     seed_xyz, rot_table, m, ndepth, nangle, grasps, counts);
+                     seed_xyz, rot_table, m, ndepth, nangle, vec16, grasps, counts);
   GN_CHECK_LAUNCH("pred_decode");
   return GN_OK;
 }

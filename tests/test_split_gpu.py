@@ -123,6 +123,17 @@ def test_crop_packed_rows_equal_padded_tiles(ref, net, monkeypatch):
         res.append(v)
     # (with m = 1000 the kernel reads seed / rot / uidx rows 0..999 of the same buffers: row stride is per seed)
     assert not torch.isnan(res[0]).any() and torch.equal(res[0], res[1])
+    # 2047 seeds as ONE cloud: 3 seeds per workgroup, the last workgroup holds a single seed
+    res = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GN_CROP_PACKED", mode)
+        v = torch.full((1, 2047 * 4, 256), float("nan"), device="cuda")
+        L.check(lib.gn_crop_unique_mlp_pool_split(xyz.data_ptr(), seed.data_ptr(), rot.data_ptr(), uidx.data_ptr(),
+                                                  ucount.data_ptr(), 1, N, 2047, 4, 64, mlp, pks.wptr, pks.bptr, v.data_ptr(), st),
+                "crop split 2047 seeds packed=" + mode)
+        torch.cuda.synchronize()
+        res.append(v)
+    assert not torch.isnan(res[0]).any() and torch.equal(res[0], res[1])
 
 
 def test_heads_and_approach_split_on_oracle_inputs(ref, truth, net):

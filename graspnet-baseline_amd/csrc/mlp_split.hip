@@ -613,6 +613,7 @@ __global__ __launch_bounds__(MLP_THREADS, MINW) void sa_xyz_split_kernel(const f
     put_x(0, v);
   }
   __syncthreads();
+  GN_PROBE_INIT();
   for (; tile < tile_end; ++tile) {
     const int g0 = tile * GPT;
     const bool has_next = tile + 1 < tile_end;
@@ -621,17 +622,25 @@ __global__ __launch_bounds__(MLP_THREADS, MINW) void sa_xyz_split_kernel(const f
       fetch_x(tile + 1, sxn, nv);
       if (tile + 2 < tile_end) sxn = fetch_i(tile + 2);
     }
+    GN_PROBE(0);
     StoreSplit e1{bufY1, sp_stride(C1), P1, lane};
     run_layer_f32_t<TP, C1>(w1, b1t, bufX + buf * TP * XS0, wave, lane, e1);
+    GN_PROBE(1);
     __syncthreads();
+    GN_PROBE(2);
     StoreSplit e2{bufY2, sp_stride(C2), P2, lane};
     run_layer_split_t_pipe<TP, C1, C2>(w2, b2t, bufY1, P1, wave, lane, e2);
     if (has_next) put_x(buf ^ 1, nv);   // published by the barrier below: no third barrier per tile (see the crop kernel)
+    GN_PROBE(3);
     __syncthreads();
+    GN_PROBE(4);
     PoolGlobal<NS, L3::NTW> e3{out + (size_t)g0 * C3, C3, lane, {}};
     run_layer_split_n<TP, C2, C3>(w3, b3, bufY2, P2, wave, lane, e3);
+    GN_PROBE(5);
+    GN_PROBE_COUNT(9, 1);
     buf ^= 1;
   }
+  GN_PROBE_FLUSH();
 }
 
 // ---- set abstraction with layer 1's per-point part hoisted (gn_point_linear), SA2-SA4: the gathered P rows are

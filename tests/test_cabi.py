@@ -41,3 +41,32 @@ def test_cpu_tensors_are_refused():
     from graspnet_amd import pointnet2_ext as E
     with pytest.raises(RuntimeError, match="CPU not supported"):
         E.ball_query(torch.zeros(1, 2, 3), torch.zeros(1, 5, 3), 0.1, 4)
+
+
+def test_header_is_plain_c_and_links_against_the_library(tmp_path):
+    """include/graspnet_hip.h is the drop-in boundary for C / C++ hosts: it must compile as C99 (no torch / C++ types in
+    the signatures) and a C program must link against the shared library and call it without a GPU (version string,
+    workspace sizes, argument refusal with a message)"""
+    import shutil
+    import subprocess
+    from graspnet_amd import _lib as L
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "host.c"
+    src.write_text('#include <stdio.h>\n#include <string.h>\n#include "graspnet_hip.h"\n'
+                   'int main(void) {\n'
+                   '  if (!gn_version() || !strlen(gn_version())) return 1;\n'
+                   '  if (gn_graspnet_workspace_bytes(8, 20000) == 0 || gn_grid_workspace_bytes(8, 20000) == 0) return 2;\n'
+                   '  if (gn_grad_workspace_bytes(2, 100, 640) != 4u * (2u * 101u + 2u * 100u + 2u * 640u)) return 3;\n'
+                   '  if (gn_ball_query(NULL, NULL, 1, 10, 4, 0.1f, 8, NULL, NULL) == 0) return 4;   /* null pointers are refused */\n'
+                   '  if (!strstr(gn_last_error(), "ball_query")) return 5;\n'
+                   '  printf("%s\\n", gn_version());\n  return 0;\n}\n')
+    exe = tmp_path / "host"
+    libdir = os.path.dirname(L.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src),
+                           "-o", str(exe), "-L", libdir, "-lgraspnet_hip", "-Wl,-rpath," + libdir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert out.stdout.strip()

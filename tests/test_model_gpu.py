@@ -440,6 +440,26 @@ def test_graph_captured_forward_matches_eager(net, clouds):
     assert torch.equal(c2, c0.flip(0)) and torch.equal(g2, g0.flip(0))
 
 
+def test_pipelined_batches_equal_one_at_a_time(net):
+    """PipelinedGraspNet: batches in flight on several streams give exactly the rows of one-at-a-time calls (each call takes its
+    workspace from its own stream's allocator pool; nothing is shared but the weights)"""
+    from graspnet_amd import PipelinedGraspNet, synthetic as S
+    batches = [S.make_batch(900 + i, 2, 6000 + 512 * (i % 3), "uniform").cuda() for i in range(7)]
+    want = []
+    for x in batches:
+        ep = net({"point_clouds": x})
+        g, c = net.decode_padded(ep)
+        want.append((ep["grasp_score_pred"].clone(), g.clone(), c.clone()))
+    torch.cuda.synchronize()
+    pipe = PipelinedGraspNet(net, depth=3)
+    tickets = [pipe.submit(x) for x in batches]
+    for t, (s0, g0, c0) in zip(reversed(tickets), reversed(want)):
+        ep, g, c = t.result()
+        assert torch.equal(c, c0) and torch.equal(g, g0) and torch.equal(ep["grasp_score_pred"], s0)
+    t = pipe.submit(batches[0]).wait()                       # stream-ordered use instead of a host wait
+    assert torch.equal(t.grasps + 0, want[0][1])
+
+
 @pytest.mark.parametrize("B,N,variant", [(1, 3000, "uniform"), (3, 4096, "surface"), (2, 9000, "uniform"),
                                          (1, 12289, "surface"), (2, 16384, "uniform"), (1, 24000, "uniform"),
                                          (1, 30000, "surface")])

@@ -129,25 +129,30 @@ __device__ __forceinline__ void load_bias_t4(const float *__restrict__ bp, int n
   for (int g = 0; g < 4; ++g) bt[g] = *reinterpret_cast<const f32x4 *>(bp + nt * 32 + 8 * g + 4 * (lane >> 5));
 }
 
-// shape of a streamed layer for this kernel family
-template <int TP, int CINP, int COUTP>
+// shape of a streamed layer for this kernel family.  CHREG: registers one weight chunk may take per wave (96 with one
+// workgroup per CU, 48 with two -- a wave then has 256 registers, 64-96 of them accumulators)
+template <int TP, int CINP, int COUTP, int CHREG = 96>
 struct StreamCfg {
   static_assert(CINP % 32 == 0 && COUTP % 32 == 0, "K in chunks of at least 32");
-  static constexpr int NT = COUTP / 32, WN = wn_for(COUTP), WM = 4 / WN, NTW = NT / WN, MT = TP / 32;
+  static constexpr int NT = COUTP / 32, MT = TP / 32, WN = wn_for(COUTP);
+  static constexpr int WM = (4 / WN < MT) ? 4 / WN : MT;      // a 32-row tile of a 64-wide layer occupies two waves only
+  static constexpr int NACTIVE = WN * WM, NTW = NT / WN;
   static_assert(NT % WN == 0 && MT % WM == 0, "tiles must divide over the waves");
-  // k-blocks per weight chunk: at least ~48 MFMAs behind every chunk load (an L2 round trip), so small layers take
-  // longer chunks
+  // k-blocks per weight chunk: at least ~48 MFMAs behind every chunk load (an L2 round trip) where the registers allow,
+  // so small layers take longer chunks
   static constexpr int MTW = MT / WM, KB = CINP / 16;
   static constexpr int KBC0 = (MTW * NTW >= 4) ? 2 : (MTW * NTW >= 2 ? 4 : 8);
-  static constexpr int KBC = (KB % KBC0 == 0) ? KBC0 : 2;
+  static constexpr int KBC1 = (NTW * KBC0 * 12 <= CHREG) ? KBC0 : (NTW * (KBC0 / 2) * 12 <= CHREG || KBC0 / 2 <= 1 ? cmax(KBC0 / 2, 1)
+                                                                                                                   : cmax(KBC0 / 4, 1));
+  static constexpr int KBC = (KB % KBC1 == 0) ? KBC1 : (KBC1 > 2 ? 2 : 1);
   static constexpr int NCH = KB / KBC;
   static_assert(KB % KBC == 0, "K must be a multiple of the chunk");
 };
 
 // one chunk of this wave's split weight fragments in registers
-template <int TP, int CINP, int COUTP>
+template <int TP, int CINP, int COUTP, int CHREG>
 struct StreamChunk {
-  using C = StreamCfg<TP, CINP, COUTP>;
+  using C = StreamCfg<TP, CINP, COUTP, CHREG>;
   bf16x8 v[C::NTW][C::KBC][3];
   __device__ __forceinline__ void load(const void *__restrict__ wq, int c, int wave, int lane) {
     const int wn = wave % C::WN;
@@ -177,14 +182,18 @@ struct StreamChunk {
 // (Requesting the NEXT layer's chunk 0 while this layer finishes -- each layer otherwise starts with an L2 round trip
 // for its first chunk, ~2.5 k cycles -- keeps three layers' chunk buffers live across the tile loop and spills
 // 250-850 bytes per lane as written; left for a restructured kernel.)
-template <int TP, int CINP, int COUTP, int XS, class Retire, class Epi>
+template <int TP, int CINP, int COUTP, int XS, int CHREG, class Retire, class Epi>
 __device__ __forceinline__ void run_layer_stream_split_t(const void *__restrict__ wq, const float *__restrict__ bias,
                                                          const __bf16 *__restrict__ xs, int xplane, int wave, int lane,
                                                          Retire &&retire, Epi &&epi) {
-  using C = StreamCfg<TP, CINP, COUTP>;
+  using C = StreamCfg<TP, CINP, COUTP, CHREG>;
   constexpr int WN = C::WN, NTW = C::NTW, MTW = C::MTW, KBC = C::KBC, NCH = C::NCH;
   const int wm = wave / WN, wn = wave % WN;
   asm volatile("" : "+s"(wq), "+s"(bias));   // keep this layer's own loads below the barrier that precedes it
+  if (C::NACTIVE < 4 && wave >= C::NACTIVE) {   // fewer tiles than waves: the others only keep the barrier count
+    retire();
+    return;
+  }
   // two accumulators per tile (mlp_split.h mfma6_2acc): the large products round once per 16-k block, the small ones
   // apart; the bias joins them in the epilogue (the accumulators start from zero)
   f32x16 acc[MTW][NTW], accl[MTW][NTW];
@@ -197,7 +206,7 @@ __device__ __forceinline__ void run_layer_stream_split_t(const void *__restrict_
         acc[mi][i][r] = 0.f;
         accl[mi][i][r] = 0.f;
       }
-  StreamChunk<TP, CINP, COUTP> first, other;
+  StreamChunk<TP, CINP, COUTP, CHREG> first, other;
   first.load(wq, 0, wave, lane);
   f32x4 bt[NTW][4];
 #pragma unroll
@@ -227,6 +236,12 @@ __device__ __forceinline__ void run_layer_stream_split_t(const void *__restrict_
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  // the bias waits in AGPRs next to the weight chunks (its only use is here): with two workgroups per CU a wave has
+  // 128 + 128 registers and the accumulators, the activation fragments and the addresses fill the VGPR half
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("" : "+a"(bt[i][g]));
   retire();
 #pragma unroll
   for (int mi = 0; mi < MTW; ++mi)
@@ -242,8 +257,12 @@ enum { PLOAD_PLAIN = 0, PLOAD_FP = 1 };
 
 // NL layers: C0 -> C1 (relu) [-> C2 (relu) [-> C3]]; the last layer goes to global (RELU_OUT), the others back to LDS.
 // CxP: padded output widths (multiples of 32 dividing over the waves); CxL: channels kept for the next layer (% 32).
-template <int LOADER, int NL, int C0, int C1P, int C1L, int C2P, int C2L, int C3P, int TP, bool RELU_OUT>
-__global__ __launch_bounds__(MLP_THREADS) void point_mlp_split_kernel(PointSplitArgs a, int ntiles) {
+// WPC workgroups per CU: 2 needs TP = 32 and K <= 256 (50 KB of LDS, <= 256 registers per lane); the stalls of one workgroup
+// (row fetch, the first weight chunk of a layer, epilogues, barriers -- 60 % of a lone workgroup's time) then lie under
+// the other's MFMAs
+template <int LOADER, int NL, int C0, int C1P, int C1L, int C2P, int C2L, int C3P, int TP, bool RELU_OUT, int WPC = 1>
+__global__ __launch_bounds__(MLP_THREADS, WPC) void point_mlp_split_kernel(PointSplitArgs a, int ntiles) {
+  constexpr int CHREG = WPC >= 2 ? 48 : 96;
   constexpr int CMAX = cmax(C0, cmax(NL > 1 ? C1L : 0, NL > 2 ? C2L : 0));
   constexpr int XS = sp_stride(CMAX), PL = TP * XS;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -284,20 +303,20 @@ __global__ __launch_bounds__(MLP_THREADS) void point_mlp_split_kernel(PointSplit
       }
     };
     if constexpr (NL == 1) {
-      run_layer_stream_split_t<TP, C0, C1P, XS>(a.w[0], a.b[0], buf, PL, wave, lane, none, to_global);
+      run_layer_stream_split_t<TP, C0, C1P, XS, CHREG>(a.w[0], a.b[0], buf, PL, wave, lane, none, to_global);
     } else {
-      run_layer_stream_split_t<TP, C0, C1P, XS>(a.w[0], a.b[0], buf, PL, wave, lane, barrier, to_lds(C1L));
+      run_layer_stream_split_t<TP, C0, C1P, XS, CHREG>(a.w[0], a.b[0], buf, PL, wave, lane, barrier, to_lds(C1L));
       GN_PROBE(2);
       __syncthreads();
       GN_PROBE(3);
       if constexpr (NL == 2) {
-        run_layer_stream_split_t<TP, C1L, C2P, XS>(a.w[1], a.b[1], buf, PL, wave, lane, none, to_global);
+        run_layer_stream_split_t<TP, C1L, C2P, XS, CHREG>(a.w[1], a.b[1], buf, PL, wave, lane, none, to_global);
       } else {
-        run_layer_stream_split_t<TP, C1L, C2P, XS>(a.w[1], a.b[1], buf, PL, wave, lane, barrier, to_lds(C2L));
+        run_layer_stream_split_t<TP, C1L, C2P, XS, CHREG>(a.w[1], a.b[1], buf, PL, wave, lane, barrier, to_lds(C2L));
         GN_PROBE(4);
         __syncthreads();
         GN_PROBE(5);
-        run_layer_stream_split_t<TP, C2L, C3P, XS>(a.w[2], a.b[2], buf, PL, wave, lane, none, to_global);
+        run_layer_stream_split_t<TP, C2L, C3P, XS, CHREG>(a.w[2], a.b[2], buf, PL, wave, lane, none, to_global);
         GN_PROBE(6);
       }
     }
@@ -307,12 +326,12 @@ __global__ __launch_bounds__(MLP_THREADS) void point_mlp_split_kernel(PointSplit
   GN_PROBE_FLUSH();
 }
 
-template <int LOADER, int NL, int C0, int C1P, int C1L, int C2P, int C2L, int C3P, int TP, bool RELU_OUT>
+template <int LOADER, int NL, int C0, int C1P, int C1L, int C2P, int C2L, int C3P, int TP, bool RELU_OUT, int WPC = 1>
 static int launch_point_split(const PointSplitArgs &a, hipStream_t s, const char *name) {
   constexpr int CMAX = cmax(C0, cmax(NL > 1 ? C1L : 0, NL > 2 ? C2L : 0));
   constexpr size_t lds = 2 * (size_t)3 * TP * sp_stride(CMAX);
-  static_assert(lds <= 160 * 1024, "LDS budget");
-  auto k = point_mlp_split_kernel<LOADER, NL, C0, C1P, C1L, C2P, C2L, C3P, TP, RELU_OUT>;
+  static_assert(lds * WPC <= 160 * 1024, "LDS budget");
+  auto k = point_mlp_split_kernel<LOADER, NL, C0, C1P, C1L, C2P, C2L, C3P, TP, RELU_OUT, WPC>;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
       hipSuccess) {
     set_error("%s: cannot reserve %zu bytes of LDS", name, lds);
@@ -327,6 +346,17 @@ static int launch_point_split(const PointSplitArgs &a, hipStream_t s, const char
 }  // namespace gn
 
 using namespace gn;
+
+// 32-row tiles, two workgroups per CU (WPC 2) against 64-row tiles, one per CU: measured in isolation at batch 8
+// (profiles/point_chain_bench.py) the heads chain gets SLOWER (69.9 -> 82.2 us: 1024 tiles each streaming the 885 KB of
+// split weights = twice the L2 -> CU traffic, and at 32 rows per weight fragment the vector memory path, 64 B/clk per CU,
+// is as long as the MFMAs) while ApproachNet gains a little (52.9 -> 49.6 us: its 128 64-row tiles fill half the chip,
+// 256 32-row tiles all of it).  Default: 2 for ApproachNet only.  GN_POINT_WPC=1 / 2 forces one shape for both (read
+// per call so that a test can A/B them).
+static int point_wpc(int dflt) {
+  const char *e = getenv("GN_POINT_WPC");
+  return e ? atoi(e) : dflt;
+}
 
 extern "C" int gn_fp_interp_mlp_split(const float *known_feat, const float *skip_feat, const float *dist2, const int32_t *idx3,
                                       int b, int n, int m, int ck, int cs, const int *mlp, const void *const *wpacked,
@@ -357,6 +387,8 @@ extern "C" int gn_approach_mlp_split(const float *x, int rows, int cin, int nout
   PointSplitArgs a{};
   for (int i = 0; i < 3; ++i) { a.w[i] = wpacked[i]; a.b[i] = bias[i]; }
   a.x = x; a.out = out; a.ldo = 302; a.ncols_out = 302; a.nrows = rows;
+  if (point_wpc(2) >= 2)
+    return launch_point_split<PLOAD_PLAIN, 3, 256, 256, 256, 384, 320, 384, 32, false, 2>(a, as_stream(stream), "approach_mlp_split");
   return launch_point_split<PLOAD_PLAIN, 3, 256, 256, 256, 384, 320, 384, 64, false>(a, as_stream(stream), "approach_mlp_split");
 }
 
@@ -372,6 +404,8 @@ extern "C" int gn_heads_mlp_split(const float *x, int rows, int cin, int nout, c
   PointSplitArgs a{};
   for (int i = 0; i < 3; ++i) { a.w[i] = wpacked[i]; a.b[i] = bias[i]; }
   a.x = x; a.out = out; a.ldo = 48; a.ncols_out = 48; a.nrows = rows;
+  if (point_wpc(1) >= 2)
+    return launch_point_split<PLOAD_PLAIN, 3, 256, 256, 256, 256, 256, 64, 32, false, 2>(a, as_stream(stream), "heads_mlp_split");
   return launch_point_split<PLOAD_PLAIN, 3, 256, 256, 256, 256, 256, 64, 64, false>(a, as_stream(stream), "heads_mlp_split");
 }
 

@@ -176,6 +176,29 @@ def test_heads_and_approach_split_on_oracle_inputs(ref, truth, net):
     assert e_or[0] >= 0.0
 
 
+@pytest.mark.parametrize("rows", [8192, 1000, 33])
+def test_point_chain_tile_shapes_are_bit_identical(net, monkeypatch, rows):
+    """the per-point chains in their two tile shapes (GN_POINT_WPC=1: 64-row tiles, one workgroup per CU; 2: 32-row tiles,
+    two per CU, idle waves in the 64-wide last layer of the heads): the k order of every dot product is the same, so the
+    outputs must be identical -- ragged last tiles included"""
+    from graspnet_amd import _lib as L
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, 256, generator=g).cuda()
+    for fn, pk, nout in ((lib.gn_heads_mlp_split, net._packed["heads_split"], 48),
+                         (lib.gn_approach_mlp_split, net._packed["approach_split"], 302)):
+        res = []
+        for wpc in ("1", "2"):
+            monkeypatch.setenv("GN_POINT_WPC", wpc)
+            o = torch.full((rows + 1, nout), float("nan"), device="cuda")
+            L.check(fn(x.data_ptr(), rows, 256, nout, pk.wptr, pk.bptr, o.data_ptr(), st), "chain")
+            torch.cuda.synchronize()
+            assert torch.isnan(o[rows]).all() and not torch.isnan(o[:rows]).any()     # nothing beyond the last row
+            res.append(o[:rows])
+        assert torch.equal(res[0], res[1])
+
+
 def test_sa_split_equals_fp32_kernels_to_rounding(net, clouds):
     """set-abstraction levels: split path vs fp32 MFMA path on the same clouds (identical sampling and neighbour lists)"""
     from graspnet_amd import GraspNet

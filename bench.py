@@ -299,8 +299,10 @@ def main():
         extra["%s_clouds" % other] = {"scenes_per_s": B * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3,
                                       "single_stream_scenes_per_s": B * k1 / e2s, "steps": args.steps,
                                       "grasps_last_step": int(l2[2].sum().item()),
-                                      "note": "%d distinct sets of %d `%s` clouds; surface scenes contain duplicate points, so "
-                                              "SA1's sampler meets exact ties and SA2-4 run their full FPS chains" % (NSETS, B, other)}
+                                      "note": "%d distinct sets of %d `%s` clouds; surface scenes hold ~1000 duplicated points each "
+                                              "(harmless to the sampler, not reported as ties) and box faces on which distinct "
+                                              "points do tie exactly in about one scene in eight; a batch with such a scene runs "
+                                              "the full SA2-4 FPS chains instead of the identity-prefix shortcut" % (NSETS, B, other)}
         del osets
         log("%s legs done" % other)
     if world == 1 and "f32" in legs and net.math_split:

@@ -72,6 +72,11 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
   // so the largest value wins and, among equal values, the lowest position = reference tie order.
   // Three rotating words: word j%3 is used by iteration j and re-armed during iteration j+2.
   __shared__ unsigned long long s_key[3];
+  // Small levels (<= 4096 positions, 48 KB): the cloud also sits in LDS, and the winner's coordinates -- the one
+  // dependent fetch of every iteration -- come from there instead of through the scalar cache from L2.  Measured on the
+  // full SA2 / SA3 / SA4 chains (profiles/fps_small_probe.py): 598 / 454 / 413 ns per iteration with the global fetch.
+  constexpr bool LDSXYZ = NT * PPT <= 4096;
+  extern __shared__ float lds_xyz[];
 
   const int b = blockIdx.x;
   xyz += (size_t)b * n * 3;
@@ -79,6 +84,8 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
   if (new_xyz) new_xyz += (size_t)b * m * 3;
   const int t = threadIdx.x;
   const int lane = t & 63;
+  if (LDSXYZ)
+    for (int e = t; e < n * 3; e += NT) lds_xyz[e] = xyz[e];
 
   float px[PPT], py[PPT], pz[PPT], tmp[PPT];
 #pragma unroll
@@ -144,9 +151,15 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
     int k = gk != 0ULL ? pos_to_k((int)~glo, bs, lg, Q, qmagic, n) : 0;
     (void)ghi;
     k = __builtin_amdgcn_readfirstlane(k < 0 ? 0 : k);
-    x1 = xyz[k * 3 + 0];
-    y1 = xyz[k * 3 + 1];
-    z1 = xyz[k * 3 + 2];
+    if (LDSXYZ) {
+      x1 = lds_xyz[k * 3 + 0];
+      y1 = lds_xyz[k * 3 + 1];
+      z1 = lds_xyz[k * 3 + 2];
+    } else {
+      x1 = xyz[k * 3 + 0];
+      y1 = xyz[k * 3 + 1];
+      z1 = xyz[k * 3 + 2];
+    }
     if (t == 0) {
       idx[j] = k;
       if (new_xyz) { new_xyz[j * 3 + 0] = x1; new_xyz[j * 3 + 1] = y1; new_xyz[j * 3 + 2] = z1; }
@@ -624,9 +637,6 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
         float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row16_max_fast(gv))));
     const bool gm = lane < G && gmax == wm;
     const unsigned klo = __builtin_amdgcn_readfirstlane(row16_max_u32_fast(gm ? gkeylo : 0u));
-    const unsigned long long gmb = __ballot(gm);
-    // a tie inside the winning group, or two groups with the same maximum (conservatively a tie)
-    const bool c_tie = (__ballot(gm && gtie) != 0ULL) || __popcll(gmb) > 1;
     const unsigned long long c_key = wm >= 0.0f ? (((unsigned long long)__float_as_uint(wm) << 32) | klo) : 0ULL;
 
     const int slot = j % 3;
@@ -637,11 +647,34 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
     __syncthreads();
     const unsigned long long gk = s_key[slot];
     const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gk);
-    if (gk == 0ULL || ((unsigned)(c_key >> 32) == (unsigned)(gk >> 32) && c_key != 0ULL && (c_tie || c_key != gk)))
-      first_tie = min(first_tie, j);
+    const unsigned ghi = __builtin_amdgcn_readfirstlane((unsigned)(gk >> 32));
     int k = gk != 0ULL ? pos_to_k((int)~glo, bs, lg, Q, qmagic, n) : 0;   // rank -> index
     k = __builtin_amdgcn_readfirstlane(k < 0 ? 0 : k);
     x1 = xyz[k * 3 + 0]; y1 = xyz[k * 3 + 1]; z1 = xyz[k * 3 + 2];
+    // ---- was this step a tie between DIFFERENT locations?  Every group (of every wave) whose maximum equals the winning
+    // value and whose candidate is not the winner itself is looked at: a tie inside the group was settled when the group
+    // was reduced (gtie); otherwise its candidate's coordinates are fetched and compared with the winner's.  A duplicate
+    // of the winning location in another region (the equal-population cuts are by ticket, so two copies of one point can
+    // land on either side of a cut) is harmless -- either copy gives the same sample -- and is no longer reported: the
+    // sampled-with-replacement `surface` clouds were flagged in 6 of 8 scenes by the per-wave test this replaces, with no
+    // tie between distinct points in any of them, and lost the SA2-4 prefix shortcut (0.95 ms of chains per batch).
+    if (gk == 0ULL) {
+      first_tie = min(first_tie, j);
+    } else {
+      const bool cand = lane < G && __float_as_uint(gmax) == ghi && (gtie || gkeylo != glo);
+      if (__ballot(cand)) {           // rare
+        bool differs = false;
+        if (cand) {
+          differs = gtie;
+          if (!differs) {
+            const int kc = pos_to_k((int)~gkeylo, bs, lg, Q, qmagic, n);
+            const int kk = kc < 0 ? 0 : kc;
+            differs = xyz[kk * 3 + 0] != x1 || xyz[kk * 3 + 1] != y1 || xyz[kk * 3 + 2] != z1;
+          }
+        }
+        if (__ballot(differs)) first_tie = min(first_tie, j);
+      }
+    }
     if (t == 0) {
       idx[j] = k;
       if (new_xyz) { new_xyz[j * 3 + 0] = x1; new_xyz[j * 3 + 1] = y1; new_xyz[j * 3 + 2] = z1; }
@@ -885,11 +918,13 @@ extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m,
   bool tie_written = false;
   static const int variant = []() { const char *e = getenv("GN_FPS_VARIANT"); return e ? atoi(e) : 4; }();
 #define GN_FPS_LAUNCH(NT, PPT)                                                                    \
-  hipLaunchKernelGGL((fps_reg_kernel<NT, PPT>), dim3(b), dim3(NT), 0, s, xyz, n, m, bs, lg, Q, qmagic, \
-                     idx, new_xyz, prefix_ok)
+  hipLaunchKernelGGL((fps_reg_kernel<NT, PPT>), dim3(b), dim3(NT), (NT) * (PPT) <= 4096 ? (size_t)n * 3 * sizeof(float) : 0, \
+                     s, xyz, n, m, bs, lg, Q, qmagic, idx, new_xyz, prefix_ok)
   if (need <= 256 * 2) GN_FPS_LAUNCH(256, 2);
   else if (need <= 256 * 4) GN_FPS_LAUNCH(256, 4);
-  else if (need <= 1024 * 2) GN_FPS_LAUNCH(1024, 2);
+  // 2048 positions: 4 waves x 8 points beat 16 waves x 2 (521 vs 598 ns per iteration, profiles/README.md: the
+  // iteration is a serial chain of ~130 instructions and three LDS round trips, and the barrier grows with the waves)
+  else if (need <= 256 * 8) GN_FPS_LAUNCH(256, 8);
   else if (need <= 1024 * 4) GN_FPS_LAUNCH(1024, 4);
   else if (need <= 1024 * 8) GN_FPS_LAUNCH(1024, 8);
   else if (need <= 1024 * 12) GN_FPS_LAUNCH(1024, 12);

@@ -75,6 +75,50 @@ def test_fps_all_points_skipped(E, oracle):
     assert torch.equal(got, want) and not got.any()
 
 
+def _first_tie_between_distinct_points(c, m):
+    """first FPS step at which the maximal running distance is shared by DIFFERENT locations (copies of one location are
+    interchangeable: either gives the same sample) -- numpy restatement of sampling_gpu.cu:105-120's update in fp32,
+    products and sums rounded one by one like the kernels (-ffp-contract=off).  Before that step the sample sequence does
+    not depend on any tie order, which is all this walk needs."""
+    c = c.astype(np.float32)
+    mag = (c[:, 0] * c[:, 0] + c[:, 1] * c[:, 1]) + c[:, 2] * c[:, 2]
+    live = mag.astype(np.float64) > 1e-3
+    tmp = np.where(live, np.float32(1e10), np.float32(-1)).astype(np.float32)
+    cur = 0
+    for j in range(1, m):
+        d = c - c[cur]
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        tmp = np.where(live, np.minimum(tmp, d2), tmp)
+        w = np.flatnonzero(tmp == tmp.max())
+        if len(w) > 1 and len(np.unique(c[w], axis=0)) > 1:
+            return j
+        cur = int(w[0])
+    return 0x7fffffff
+
+
+@pytest.mark.parametrize("variant,seed", [("uniform", 1000), ("uniform", 1024), ("surface", 1000), ("surface", 1016)])
+def test_fps_tie_step_is_exact(variant, seed):
+    """the SA1 sampler's tie report (first step with a tie between distinct locations; lets SA2-4 return the identity
+    prefix when it lies beyond their sample count) against the walk above: fp32 ties between distinct points do occur
+    (about one uniform cloud in five within 2048 steps), while the 1000 duplicated points of a `surface` cloud must NOT be
+    reported, wherever the region cuts put the copies"""
+    from graspnet_amd import _lib as L
+    lib = L.lib()
+    x = _cloud(seed, 8, 20000, variant)
+    xd = x.cuda()
+    ws = torch.empty(max(int(lib.gn_fps_workspace_bytes(8, 20000)), 16), dtype=torch.uint8, device="cuda")
+    idx = torch.empty(8, 2048, dtype=torch.int32, device="cuda")
+    want = [_first_tie_between_distinct_points(x[i].numpy(), 2048) for i in range(8)]
+    for _ in range(3):       # the slot a point lands in depends on atomic ticket order: the report must not
+        tie = torch.full((8,), -7, dtype=torch.int32, device="cuda")
+        L.check(lib.gn_furthest_point_sampling(xd.data_ptr(), 8, 20000, 2048, ws.data_ptr(), idx.data_ptr(), None,
+                                               tie.data_ptr(), None, torch.cuda.current_stream().cuda_stream), "fps")
+        torch.cuda.synchronize()
+        assert tie.cpu().tolist() == want
+    if (variant, seed) == ("surface", 1000):      # no tie between distinct points in these 8 scenes: the SA2-4 shortcut holds
+        assert min(want) == 0x7fffffff
+
+
 SA = [(20000, 2048, 0.04, 64), (2048, 1024, 0.1, 32), (1024, 512, 0.2, 16), (512, 256, 0.3, 16)]
 
 

@@ -426,7 +426,9 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
   static_assert(PPT % G == 0, "slots per lane must split into 8 groups");
   constexpr int YB = 1024;             // y bins per slab
   extern __shared__ int lds_i[];
-  int *perm = lds_i;                   // [NW*CELL]
+  int *perm = lds_i;                   // [NW*CELL]  slot -> (0xffff - rank) << 16 | index of its point, 0 = empty:
+                                       // the low word of the arg-max key as it stands, so neither the group reduce
+                                       // (index -> rank) nor the winner fetch (rank -> index) computes anything
   int *hx = perm + NW * CELL;          // [FPS_BINS]
   int *hy = hx + FPS_BINS;             // [8][YB]
   int *scr = hy + 8 * YB;              // [64]
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
     if (lane == 0) { scrf[wave * 4 + 0] = a0; scrf[wave * 4 + 1] = a1; scrf[wave * 4 + 2] = a2; scrf[wave * 4 + 3] = a3; }
   }
   for (int i = t; i < FPS_BINS + 8 * YB; i += NT) hx[i] = 0;
-  for (int i = t; i < NW * CELL; i += NT) perm[i] = -1;
+  for (int i = t; i < NW * CELL; i += NT) perm[i] = 0;
   __syncthreads();
   xmn = scrf[0]; xmx = scrf[1]; ymn = scrf[2]; ymx = scrf[3];
   for (int w = 1; w < NW; ++w) {
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
       const int cy = min(q2 / T2, 7);
       const int r = min(q2 - cy * T2, 64 * SG - 1);
       const int w = (sl + 3 * cy) & 7;                 // region (sl,cy) -> wave, group cy
-      perm[w * CELL + (cy * SG + r / 64) * 64 + (r & 63)] = k;
+      perm[w * CELL + (cy * SG + r / 64) * 64 + (r & 63)] = (int)(((0xffffu - (unsigned)rank_of(k)) << 16) | (unsigned)k);
     }
   }
   __syncthreads();
@@ -535,9 +537,10 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
 #pragma unroll
     for (int q = 0; q < SG; ++q) {
       const int s = g * SG + q;
-      const int k = perm[wave * CELL + s * 64 + lane];
+      const int pk = perm[wave * CELL + s * 64 + lane];
+      const int k = pk & 0xffff;
       float x = 0.f, y = 0.f, z = 0.f, t0 = -1.0f;
-      if (k >= 0) {
+      if (pk != 0) {
         x = xyz[k * 3 + 0]; y = xyz[k * 3 + 1]; z = xyz[k * 3 + 2];
         const float mag = (x * x) + (y * y) + (z * z);
         t0 = ((double)mag <= 1e-3) ? -1.0f : 1e10f;     // sampling_gpu.cu:105-106, sampling.cpp:78-80
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
     if (lane == g) { gx0 = x0; gx1 = x1_; gy0 = y0; gy1 = y1_; gz0 = z0; gz1 = z1_; }
   }
   float gmax = INFINITY;       // cached max of the group's running distances (inf = not computed yet)
-  unsigned gkeylo = 0u;        // ~rank of the group's candidate
+  unsigned gkeylo = 0u;        // key word of the group's candidate: (0xffff - rank) << 16 | index
   bool gtie = false;           // the group's max is shared by different locations
 
   float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
@@ -608,9 +611,9 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
           for (int q = 0; q < SG; ++q) {
             const int s = g * SG + q;
             if (tmp[s] == wmax) {
-              const int k = perm[wave * CELL + s * 64 + lane];
-              if (k >= 0) {
-                myr = min(myr, rank_of(k));
+              const int pk = perm[wave * CELL + s * 64 + lane];
+              if (pk != 0) {
+                myr = min(myr, (int)~(unsigned)pk);      // ~key: smallest = lowest rank
                 lx0 = fminf(lx0, px[s]); lx1 = fmaxf(lx1, px[s]); ly0 = fminf(ly0, py[s]); ly1 = fmaxf(ly1, py[s]);
                 lz0 = fminf(lz0, pz[s]); lz1 = fmaxf(lz1, pz[s]);
               }
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
         } else {
           const int src = __ffsll((long long)eq) - 1;
           const int kc = perm[wave * CELL + bslot * 64 + lane];
-          wrank = rank_of(__builtin_amdgcn_readlane(kc, src));
+          wrank = (int)~(unsigned)__builtin_amdgcn_readlane(kc, src);
         }
       }
       if (lane == g) {
@@ -648,8 +651,7 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
     const unsigned long long gk = s_key[slot];
     const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gk);
     const unsigned ghi = __builtin_amdgcn_readfirstlane((unsigned)(gk >> 32));
-    int k = gk != 0ULL ? pos_to_k((int)~glo, bs, lg, Q, qmagic, n) : 0;   // rank -> index
-    k = __builtin_amdgcn_readfirstlane(k < 0 ? 0 : k);
+    const int k = gk != 0ULL ? (int)(glo & 0xffffu) : 0;
     x1 = xyz[k * 3 + 0]; y1 = xyz[k * 3 + 1]; z1 = xyz[k * 3 + 2];
     // ---- was this step a tie between DIFFERENT locations?  Every group (of every wave) whose maximum equals the winning
     // value and whose candidate is not the winner itself is looked at: a tie inside the group was settled when the group
@@ -667,8 +669,7 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
         if (cand) {
           differs = gtie;
           if (!differs) {
-            const int kc = pos_to_k((int)~gkeylo, bs, lg, Q, qmagic, n);
-            const int kk = kc < 0 ? 0 : kc;
+            const int kk = (int)(gkeylo & 0xffffu);
             differs = xyz[kk * 3 + 0] != x1 || xyz[kk * 3 + 1] != y1 || xyz[kk * 3 + 2] != z1;
           }
         }

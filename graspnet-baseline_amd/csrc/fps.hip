@@ -418,6 +418,27 @@ __global__ __launch_bounds__(1024) void fps_spatial_kernel(const float *__restri
 // re-reduces only that group) while its other 7 groups keep their cached (max, rank).  Lanes 0..7
 // of a wave hold the state of its 8 groups (box, max, ~rank, tie), so the skip test of all groups
 // is one short vector sequence and the wave's candidate is a 16-lane DPP reduction.
+// phase probe of the region kernel (instrumented build only, profiles/build_probe.sh): wave-uniform s_memtime deltas
+// accumulated in SGPRs -- 0 skip test, 1 active groups, 2 wave candidate + atomic, 3 barrier, 4 key read-back + winner
+// fetch, 5 tie check + bookkeeping; 6 = number of active groups
+#ifdef GN_PHASE_PROBE
+__device__ unsigned long long gn_fps_probe[8 * 8];
+#define FPS_PROBE_INIT() unsigned long long fp_[8] = {}; unsigned long long fl_ = __builtin_amdgcn_s_memtime()
+#define FPS_PROBE(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); fp_[i] += n_ - fl_; fl_ = n_; } while (0)
+#define FPS_PROBE_ADD(i, v) fp_[i] += (unsigned long long)(v)
+#define FPS_PROBE_USE(v) asm volatile("" :: "s"(__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)(v)))))
+#define FPS_PROBE_FLUSH() do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; ++i_) gn_fps_probe[(threadIdx.x >> 6) * 8 + i_] = fp_[i_]; } while (0)
+extern "C" int gn_phase_probe_read_fps(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(gn_fps_probe), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#else
+#define FPS_PROBE_INIT()
+#define FPS_PROBE(i)
+#define FPS_PROBE_ADD(i, v)
+#define FPS_PROBE_USE(v)
+#define FPS_PROBE_FLUSH()
+#endif
+
 template <int PPT>
 __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict__ xyz, int n, int m, int bs, int lg,
                                                          int Q, unsigned qmagic, int32_t *__restrict__ idx,
@@ -566,13 +587,17 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
   __syncthreads();
 
   int first_tie = 0x7fffffff;
+  FPS_PROBE_INIT();
   for (int j = 1; j < m; ++j) {
+    FPS_PROBE(5);
     // ---- which of this wave's groups can change?  (lane g tests group g)
     const float ex = fmaxf(fmaxf(gx0 - x1, x1 - gx1), 0.f);
     const float ey = fmaxf(fmaxf(gy0 - y1, y1 - gy1), 0.f);
     const float ez = fmaxf(fmaxf(gz0 - z1, z1 - gz1), 0.f);
     const float lb = (ex * ex + ey * ey + ez * ez) * 0.99999f;
     const unsigned amask = (unsigned)__ballot(lane < G && !(lb >= gmax)) & 0xffu;
+    FPS_PROBE(0);
+    FPS_PROBE_ADD(6, __popc(amask));
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       if (!((amask >> g) & 1u)) continue;      // wave-uniform
@@ -591,12 +616,7 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
         best = gt ? d2 : best;
         bslot = gt ? s : bslot;
       }
-      const float rmax = row16_max_fast(best);
-      const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rmax), 0));
-      const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rmax), 16));
-      const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rmax), 32));
-      const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rmax), 48));
-      const float wmax = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+      const float wmax = wave_max_fast(best);
       const bool mine = best == wmax;
       const unsigned long long eq = __ballot(mine);
       int wrank = 0;
@@ -634,25 +654,28 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
         gtie = ctie;
       }
     }
-    // ---- the wave's candidate: best of its 8 groups (largest value, then smallest rank)
-    const float gv = lane < G ? gmax : -2.0f;
-    const float wm = __builtin_bit_cast(
-        float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row16_max_fast(gv))));
-    const bool gm = lane < G && gmax == wm;
-    const unsigned klo = __builtin_amdgcn_readfirstlane(row16_max_u32_fast(gm ? gkeylo : 0u));
-    const unsigned long long c_key = wm >= 0.0f ? (((unsigned long long)__float_as_uint(wm) << 32) | klo) : 0ULL;
-
+    FPS_PROBE(1);
+    // ---- every group folds its own candidate into the iteration's LDS word (lanes 0..7 of each wave, one ds_max_u64
+    // with eight lanes on one address): the phase probe put the former per-wave pre-reduction -- two DPP chains, two
+    // readfirstlanes, a ballot -- at ~440 cycles of the ~2200-cycle iteration, on every wave, every iteration.
+    // fps.hip is compiled with the atomic optimizer off (csrc/Makefile): it would rebuild that reduction around the atomic.
     const int slot = j % 3;
-    if (lane == 0) {
-      atomicMax(&s_key[slot], c_key);
-      if (t == 0) s_key[(j + 1) % 3] = 0ULL;
+    if (lane < G) {
+      const unsigned long long key_l =
+          gmax >= 0.0f ? (((unsigned long long)__float_as_uint(gmax) << 32) | gkeylo) : 0ULL;   // all skipped: loses to anything
+      atomicMax(&s_key[slot], key_l);
     }
+    if (t == 0) s_key[(j + 1) % 3] = 0ULL;
+    FPS_PROBE(2);
     __syncthreads();
+    FPS_PROBE(3);
     const unsigned long long gk = s_key[slot];
     const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gk);
     const unsigned ghi = __builtin_amdgcn_readfirstlane((unsigned)(gk >> 32));
     const int k = gk != 0ULL ? (int)(glo & 0xffffu) : 0;
     x1 = xyz[k * 3 + 0]; y1 = xyz[k * 3 + 1]; z1 = xyz[k * 3 + 2];
+    FPS_PROBE_USE(x1 + y1 + z1);
+    FPS_PROBE(4);
     // ---- was this step a tie between DIFFERENT locations?  Every group (of every wave) whose maximum equals the winning
     // value and whose candidate is not the winner itself is looked at: a tie inside the group was settled when the group
     // was reduced (gtie); otherwise its candidate's coordinates are fetched and compared with the winner's.  A duplicate
@@ -681,6 +704,7 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
       if (new_xyz) { new_xyz[j * 3 + 0] = x1; new_xyz[j * 3 + 1] = y1; new_xyz[j * 3 + 2] = z1; }
     }
   }
+  FPS_PROBE_FLUSH();
   if (tie_out) {
     __shared__ int s_tie;
     if (t == 0) s_tie = 0x7fffffff;

@@ -8,7 +8,7 @@ FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -I$ROOT/incl
 for f in $SRC/*.hip $SRC/*.cpp; do
   o=$HERE/probe/obj/$(basename $f).o
   X=""
-  case $(basename $f) in mlp_split.hip|mlp_point_split.hip) X="-mllvm -amdgpu-mfma-vgpr-form";; esac   # as csrc/Makefile
+  case $(basename $f) in mlp_split.hip|mlp_point_split.hip) X="-mllvm -amdgpu-mfma-vgpr-form";; fps.hip) X="-mllvm -amdgpu-atomic-optimizer-strategy=None";; esac   # as csrc/Makefile
   if [ ! -f $o ] || [ $f -nt $o ] || [ $SRC/mlp_core.h -nt $o ] || [ $SRC/mlp_split.h -nt $o ]; then /opt/rocm/bin/hipcc $FLAGS $X -x hip -c $f -o $o & fi
 done
 wait

@@ -600,7 +600,8 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
     FPS_PROBE_ADD(6, __popc(amask));
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      if (!((amask >> g) & 1u)) continue;      // wave-uniform
+      if (__builtin_expect(!((amask >> g) & 1u), 1)) continue;      // wave-uniform; a wave has 0.47 active groups per step on
+                                                                     // average: the fall-through path is the skip
       float best = -1.0f;
       int bslot = 0;
       bool tie = false;
@@ -616,6 +617,9 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
         best = gt ? d2 : best;
         bslot = gt ? s : bslot;
       }
+      // every lane asks for its own candidate's key word now: the LDS round trip runs under the DPP reduction instead of
+      // after it (only the winning lane's word is used, and only on the common no-tie path)
+      const int kc = perm[wave * CELL + bslot * 64 + lane];
       const float wmax = wave_max_fast(best);
       const bool mine = best == wmax;
       const unsigned long long eq = __ballot(mine);
@@ -644,7 +648,6 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
                  (-wave_max(-lz0) != wave_max(lz1));
         } else {
           const int src = __ffsll((long long)eq) - 1;
-          const int kc = perm[wave * CELL + bslot * 64 + lane];
           wrank = (int)~(unsigned)__builtin_amdgcn_readlane(kc, src);
         }
       }

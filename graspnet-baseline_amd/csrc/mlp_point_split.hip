@@ -182,12 +182,16 @@ struct StreamChunk {
 // (Requesting the NEXT layer's chunk 0 while this layer finishes -- each layer otherwise starts with an L2 round trip
 // for its first chunk, ~2.5 k cycles -- keeps three layers' chunk buffers live across the tile loop and spills
 // 250-850 bytes per lane as written; left for a restructured kernel.)
-template <int TP, int CINP, int COUTP, int XS, int CHREG, class Retire, class Epi>
+// BLOCK2: the layer is two independent halves side by side (OperationNet | ToleranceNet, modules.py:171-175,216-220, packed
+// as ONE block-diagonal matrix): output channels of the first half read only the first half of K, the others only the
+// second, and the other K chunks of a wave's weight slice are all zeros -- they are not streamed and not multiplied.
+template <int TP, int CINP, int COUTP, int XS, int CHREG, bool BLOCK2, class Retire, class Epi>
 __device__ __forceinline__ void run_layer_stream_split_t(const void *__restrict__ wq, const float *__restrict__ bias,
                                                          const __bf16 *__restrict__ xs, int xplane, int wave, int lane,
                                                          Retire &&retire, Epi &&epi) {
   using C = StreamCfg<TP, CINP, COUTP, CHREG>;
   constexpr int WN = C::WN, NTW = C::NTW, MTW = C::MTW, KBC = C::KBC, NCH = C::NCH;
+  static_assert(!BLOCK2 || (WN % 2 == 0 && NCH % 4 == 0), "halves must fall on wave and (even) chunk boundaries");
   const int wm = wave / WN, wn = wave % WN;
   asm volatile("" : "+s"(wq), "+s"(bias));   // keep this layer's own loads below the barrier that precedes it
   if (C::NACTIVE < 4 && wave >= C::NACTIVE) {   // fewer tiles than waves: the others only keep the barrier count
@@ -207,13 +211,14 @@ __device__ __forceinline__ void run_layer_stream_split_t(const void *__restrict_
         accl[mi][i][r] = 0.f;
       }
   StreamChunk<TP, CINP, COUTP, CHREG> first, other;
-  first.load(wq, 0, wave, lane);
+  const int c0 = BLOCK2 ? (wn >= WN / 2 ? NCH / 2 : 0) : 0, c1 = BLOCK2 ? c0 + NCH / 2 : NCH;   // c0 even: buffer parity = c & 1
+  first.load(wq, c0, wave, lane);
   f32x4 bt[NTW][4];
 #pragma unroll
   for (int i = 0; i < NTW; ++i) load_bias_t4(bias, wn * NTW + i, lane, bt[i]);
 #pragma unroll 2
-  for (int c = 0; c < NCH; ++c) {
-    if (c + 1 < NCH) {
+  for (int c = c0; c < c1; ++c) {
+    if (c + 1 < c1) {
       if (c & 1) first.load(wq, c + 1, wave, lane); else other.load(wq, c + 1, wave, lane);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -260,7 +265,7 @@ enum { PLOAD_PLAIN = 0, PLOAD_FP = 1 };
 // WPC workgroups per CU: 2 needs TP = 32 and K <= 256 (50 KB of LDS, <= 256 registers per lane); the stalls of one workgroup
 // (row fetch, the first weight chunk of a layer, epilogues, barriers -- 60 % of a lone workgroup's time) then lie under
 // the other's MFMAs
-template <int LOADER, int NL, int C0, int C1P, int C1L, int C2P, int C2L, int C3P, int TP, bool RELU_OUT, int WPC = 1>
+template <int LOADER, int NL, int C0, int C1P, int C1L, int C2P, int C2L, int C3P, int TP, bool RELU_OUT, int WPC = 1, bool BD2 = false>
 __global__ __launch_bounds__(MLP_THREADS, WPC) void point_mlp_split_kernel(PointSplitArgs a, int ntiles) {
   constexpr int CHREG = WPC >= 2 ? 48 : 96;
   constexpr int CMAX = cmax(C0, cmax(NL > 1 ? C1L : 0, NL > 2 ? C2L : 0));
@@ -303,20 +308,20 @@ __global__ __launch_bounds__(MLP_THREADS, WPC) void point_mlp_split_kernel(Point
       }
     };
     if constexpr (NL == 1) {
-      run_layer_stream_split_t<TP, C0, C1P, XS, CHREG>(a.w[0], a.b[0], buf, PL, wave, lane, none, to_global);
+      run_layer_stream_split_t<TP, C0, C1P, XS, CHREG, false>(a.w[0], a.b[0], buf, PL, wave, lane, none, to_global);
     } else {
-      run_layer_stream_split_t<TP, C0, C1P, XS, CHREG>(a.w[0], a.b[0], buf, PL, wave, lane, barrier, to_lds(C1L));
+      run_layer_stream_split_t<TP, C0, C1P, XS, CHREG, false>(a.w[0], a.b[0], buf, PL, wave, lane, barrier, to_lds(C1L));
       GN_PROBE(2);
       __syncthreads();
       GN_PROBE(3);
       if constexpr (NL == 2) {
-        run_layer_stream_split_t<TP, C1L, C2P, XS, CHREG>(a.w[1], a.b[1], buf, PL, wave, lane, none, to_global);
+        run_layer_stream_split_t<TP, C1L, C2P, XS, CHREG, BD2>(a.w[1], a.b[1], buf, PL, wave, lane, none, to_global);
       } else {
-        run_layer_stream_split_t<TP, C1L, C2P, XS, CHREG>(a.w[1], a.b[1], buf, PL, wave, lane, barrier, to_lds(C2L));
+        run_layer_stream_split_t<TP, C1L, C2P, XS, CHREG, BD2>(a.w[1], a.b[1], buf, PL, wave, lane, barrier, to_lds(C2L));
         GN_PROBE(4);
         __syncthreads();
         GN_PROBE(5);
-        run_layer_stream_split_t<TP, C2L, C3P, XS, CHREG>(a.w[2], a.b[2], buf, PL, wave, lane, none, to_global);
+        run_layer_stream_split_t<TP, C2L, C3P, XS, CHREG, false>(a.w[2], a.b[2], buf, PL, wave, lane, none, to_global);
         GN_PROBE(6);
       }
     }
@@ -326,12 +331,12 @@ __global__ __launch_bounds__(MLP_THREADS, WPC) void point_mlp_split_kernel(Point
   GN_PROBE_FLUSH();
 }
 
-template <int LOADER, int NL, int C0, int C1P, int C1L, int C2P, int C2L, int C3P, int TP, bool RELU_OUT, int WPC = 1>
+template <int LOADER, int NL, int C0, int C1P, int C1L, int C2P, int C2L, int C3P, int TP, bool RELU_OUT, int WPC = 1, bool BD2 = false>
 static int launch_point_split(const PointSplitArgs &a, hipStream_t s, const char *name) {
   constexpr int CMAX = cmax(C0, cmax(NL > 1 ? C1L : 0, NL > 2 ? C2L : 0));
   constexpr size_t lds = 2 * (size_t)3 * TP * sp_stride(CMAX);
   static_assert(lds * WPC <= 160 * 1024, "LDS budget");
-  auto k = point_mlp_split_kernel<LOADER, NL, C0, C1P, C1L, C2P, C2L, C3P, TP, RELU_OUT, WPC>;
+  auto k = point_mlp_split_kernel<LOADER, NL, C0, C1P, C1L, C2P, C2L, C3P, TP, RELU_OUT, WPC, BD2>;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
       hipSuccess) {
     set_error("%s: cannot reserve %zu bytes of LDS", name, lds);
@@ -404,9 +409,16 @@ extern "C" int gn_heads_mlp_split(const float *x, int rows, int cin, int nout, c
   PointSplitArgs a{};
   for (int i = 0; i < 3; ++i) { a.w[i] = wpacked[i]; a.b[i] = bias[i]; }
   a.x = x; a.out = out; a.ldo = 48; a.ncols_out = 48; a.nrows = rows;
-  if (point_wpc(1) >= 2)
-    return launch_point_split<PLOAD_PLAIN, 3, 256, 256, 256, 256, 256, 64, 32, false, 2>(a, as_stream(stream), "heads_mlp_split");
-  return launch_point_split<PLOAD_PLAIN, 3, 256, 256, 256, 256, 256, 64, 64, false>(a, as_stream(stream), "heads_mlp_split");
+  // layer 2 is block-diagonal (two 128 -> 128 maps): each wave streams and multiplies its own half of K only.
+  // GN_HEADS_DENSE=1 multiplies the zero blocks too (the round-1 form; A/B in tests/test_split_gpu.py)
+  const char *de = getenv("GN_HEADS_DENSE");
+  const bool dense = de && atoi(de) != 0;
+  if (point_wpc(1) >= 2) {
+    if (dense) return launch_point_split<PLOAD_PLAIN, 3, 256, 256, 256, 256, 256, 64, 32, false, 2>(a, as_stream(stream), "heads_mlp_split");
+    return launch_point_split<PLOAD_PLAIN, 3, 256, 256, 256, 256, 256, 64, 32, false, 2, true>(a, as_stream(stream), "heads_mlp_split");
+  }
+  if (dense) return launch_point_split<PLOAD_PLAIN, 3, 256, 256, 256, 256, 256, 64, 64, false>(a, as_stream(stream), "heads_mlp_split");
+  return launch_point_split<PLOAD_PLAIN, 3, 256, 256, 256, 256, 256, 64, 64, false, 1, true>(a, as_stream(stream), "heads_mlp_split");
 }
 
 extern "C" int gn_point_linear_split(const float *x, int rows, int cin, int cout, const void *wpacked, const float *bias,

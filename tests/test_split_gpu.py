@@ -189,14 +189,16 @@ def test_point_chain_tile_shapes_are_bit_identical(net, monkeypatch, rows):
     for fn, pk, nout in ((lib.gn_heads_mlp_split, net._packed["heads_split"], 48),
                          (lib.gn_approach_mlp_split, net._packed["approach_split"], 302)):
         res = []
-        for wpc in ("1", "2"):
+        for wpc, dense in (("1", "0"), ("2", "0"), ("1", "1"), ("2", "1")):
+            # GN_HEADS_DENSE=1: the heads' block-diagonal layer 2 multiplies its zero blocks too (adds exact zeros)
             monkeypatch.setenv("GN_POINT_WPC", wpc)
+            monkeypatch.setenv("GN_HEADS_DENSE", dense)
             o = torch.full((rows + 1, nout), float("nan"), device="cuda")
             L.check(fn(x.data_ptr(), rows, 256, nout, pk.wptr, pk.bptr, o.data_ptr(), st), "chain")
             torch.cuda.synchronize()
             assert torch.isnan(o[rows]).all() and not torch.isnan(o[:rows]).any()     # nothing beyond the last row
             res.append(o[:rows])
-        assert torch.equal(res[0], res[1])
+        assert all(torch.equal(res[0], r) for r in res[1:])
 
 
 def test_sa_split_equals_fp32_kernels_to_rounding(net, clouds):

@@ -548,6 +548,9 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_packed_split_kernel(const fl
   GN_PROBE_FLUSH();
 }
 
+// a neighbour's and its centre's coordinates as loaded, before (p - c) / radius
+struct RawRow { float p0, p1, p2, c0, c1, c2; };
+
 // ---- set abstraction, SA1 (no input features): SharedMLP[3,64,64,128] + max over 64 neighbours
 // (pointnet2_utils.py:344-355 + pointnet2_modules.py:251-257).  Layer 1 (K = 3) on the fp32 MFMA, layers 2-3 split.
 template <int C1, int C2, int C3, int NS, int TP, int MINW>
@@ -583,33 +586,43 @@ __global__ __launch_bounds__(MLP_THREADS, MINW) void sa_xyz_split_kernel(const f
   if (tile >= tile_end) return;
   // the neighbour index of the tile after next is loaded while the next tile's coordinates are gathered (see the
   // hoisted kernel below)
-  auto fetch_i = [&](int tl) -> int { return tid < TP ? idx[(size_t)tl * GPT * NS + tid] : 0; };
-  auto fetch_x = [&](int tl, int src, f32x4 &v) {
+  auto fetch_i = [&](int tl) -> int { return idx[(size_t)tl * GPT * NS + min(tid, TP - 1)]; };   // unconditional: see fetch_x
+  // fetch_x only ISSUES the six loads of a row (neighbour and centre coordinates); the subtraction and the division by the
+  // radius happen in put_x, a layer later.  Done at the fetch they made wave 0 -- the only wave whose rows are used -- wait
+  // out the loads' L2 round trip in front of a barrier while the other three waves waited for it (phase probe of the SA2
+  // kernel: 2 320 against ~700 cycles in that phase per 64-row tile; 0.1465 -> 0.1399 ms uninstrumented).
+  // Every thread loads (threads beyond the tile's rows: row 0 and the last group's centre, never used): a branch around
+  // the loads needs a merge value for the others, i.e. writes into registers that are still load destinations, and such
+  // a write waits for ALL outstanding memory operations; and with 64 neighbours per group the centre is the same for a
+  // whole wave -- a scalar load -- which inside the branch was waited for on the spot to be copied into vector registers.
+  auto fetch_x = [&](int tl, int src, RawRow &r) {
     const int g0 = tl * GPT;
     const int b = g0 / np;
-    v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (tid < TP) {
-      const float *c = new_xyz + ((size_t)g0 + tid / NS) * 3;
-      const float *px = xyz + (size_t)b * n * 3;
-      v[0] = (px[src * 3 + 0] - c[0]) / radius;   // pointnet2_utils.py:346-348
-      v[1] = (px[src * 3 + 1] - c[1]) / radius;
-      v[2] = (px[src * 3 + 2] - c[2]) / radius;
-    }
+    const float *c = new_xyz + ((size_t)g0 + min(tid / NS, GPT - 1)) * 3;
+    const float *px = xyz + (size_t)b * n * 3;
+    r.p0 = px[src * 3 + 0]; r.p1 = px[src * 3 + 1]; r.p2 = px[src * 3 + 2];
+    r.c0 = c[0]; r.c1 = c[1]; r.c2 = c[2];
   };
-  auto put_x = [&](int buf, const f32x4 &v) {
+  auto put_x = [&](int buf, const RawRow &r) {
     if (tid < TP) {
       float *x = bufX + buf * TP * XS0 + tid * XS0;
-      *reinterpret_cast<f32x4 *>(x) = v;
+      // pointnet2_utils.py:346-348
+      *reinterpret_cast<f32x4 *>(x) = f32x4{(r.p0 - r.c0) / radius, (r.p1 - r.c1) / radius, (r.p2 - r.c2) / radius, 0.f};
       *reinterpret_cast<f32x4 *>(x + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   int buf = 0;
   int sxn;
+  RawRow nv;                 // rows of the next tile, fetched while the previous one was in layer 3
   {
-    f32x4 v;
+    RawRow v;
     sxn = fetch_i(tile);
     fetch_x(tile, sxn, v);
-    if (tile + 1 < tile_end) sxn = fetch_i(tile + 1);
+    if (tile + 1 < tile_end) {
+      sxn = fetch_i(tile + 1);
+      fetch_x(tile + 1, sxn, nv);
+      if (tile + 2 < tile_end) sxn = fetch_i(tile + 2);
+    }
     put_x(0, v);
   }
   __syncthreads();
@@ -617,11 +630,6 @@ __global__ __launch_bounds__(MLP_THREADS, MINW) void sa_xyz_split_kernel(const f
   for (; tile < tile_end; ++tile) {
     const int g0 = tile * GPT;
     const bool has_next = tile + 1 < tile_end;
-    f32x4 nv;
-    if (has_next) {                               // in flight under the three layers
-      fetch_x(tile + 1, sxn, nv);
-      if (tile + 2 < tile_end) sxn = fetch_i(tile + 2);
-    }
     GN_PROBE(0);
     StoreSplit e1{bufY1, sp_stride(C1), P1, lane};
     run_layer_f32_t<TP, C1>(w1, b1t, bufX + buf * TP * XS0, wave, lane, e1);
@@ -633,6 +641,15 @@ __global__ __launch_bounds__(MLP_THREADS, MINW) void sa_xyz_split_kernel(const f
     if (has_next) put_x(buf ^ 1, nv);   // published by the barrier below: no third barrier per tile (see the crop kernel)
     GN_PROBE(3);
     __syncthreads();
+    // The rows of the tile AFTER NEXT are requested here, in front of layer 3 (they are put into LDS behind the next
+    // tile's layer 2).  Their addresses depend on an index loaded a tile ago; the wait for it is a vmcnt(0) -- loads and
+    // stores share the counter and the compiler cannot count across the loop edge -- so it also waits for everything
+    // issued since: at the loop top that included the pooled rows stored a few instructions earlier; here the last
+    // stores are two layers old.  (With the unconditional loads of fetch_x: 0.1576 -> 0.1544 ms at the SA1 shape.)
+    if (tile + 2 < tile_end) {
+      fetch_x(tile + 2, sxn, nv);
+      if (tile + 3 < tile_end) sxn = fetch_i(tile + 3);
+    }
     GN_PROBE(4);
     PoolGlobal<NS, L3::NTW> e3{out + (size_t)g0 * C3, C3, lane, {}};
     run_layer_split_n<TP, C2, C3>(w3, b3, bufY2, P2, wave, lane, e3);
@@ -689,7 +706,7 @@ __global__ __launch_bounds__(NWV * 64) void sa_hoist_split_kernel(const float *_
     const int32_t *ixb = idx + (size_t)tl * GPT * NS;
 #pragma unroll
     for (int mi = 0; mi < MTW; ++mi) ix[mi] = ixb[mi * 32 + (lane & 31)];
-    sx = tid < TP ? ixb[tid] : 0;
+    sx = ixb[min(tid, TP - 1)];
   };
   auto fetch_p = [&](int tl, const int (&ix)[MTW], f32x4 (&pf)[MTW][4]) {
     const int b = (tl * GPT) / np;
@@ -701,22 +718,27 @@ __global__ __launch_bounds__(NWV * 64) void sa_hoist_split_kernel(const float *_
       for (int g = 0; g < 4; ++g) pf[mi][g] = *reinterpret_cast<const f32x4 *>(row + 8 * g);
     }
   };
-  auto fetch_x = [&](int tl, int src, f32x4 &v) {
+  // fetch_x only ISSUES the six loads of a row (neighbour and centre coordinates); the subtraction and the division by the
+  // radius happen in put_x, a layer later.  Done at the fetch they made wave 0 -- the only wave whose rows are used -- wait
+  // out the loads' L2 round trip in front of a barrier while the other three waves waited for it (phase probe of the SA2
+  // kernel: 2 320 against ~700 cycles in that phase per 64-row tile; 0.1465 -> 0.1399 ms uninstrumented).
+  // Every thread loads (threads beyond the tile's rows: row 0 and the last group's centre, never used): a branch around
+  // the loads needs a merge value for the others, i.e. writes into registers that are still load destinations, and such
+  // a write waits for ALL outstanding memory operations; and with 64 neighbours per group the centre is the same for a
+  // whole wave -- a scalar load -- which inside the branch was waited for on the spot to be copied into vector registers.
+  auto fetch_x = [&](int tl, int src, RawRow &r) {
     const int g0 = tl * GPT;
     const int b = g0 / np;
-    v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (tid < TP) {
-      const float *c = new_xyz + ((size_t)g0 + tid / NS) * 3;
-      const float *px = xyz + (size_t)b * n * 3;
-      v[0] = (px[src * 3 + 0] - c[0]) / radius;   // pointnet2_utils.py:346-348
-      v[1] = (px[src * 3 + 1] - c[1]) / radius;
-      v[2] = (px[src * 3 + 2] - c[2]) / radius;
-    }
+    const float *c = new_xyz + ((size_t)g0 + min(tid / NS, GPT - 1)) * 3;
+    const float *px = xyz + (size_t)b * n * 3;
+    r.p0 = px[src * 3 + 0]; r.p1 = px[src * 3 + 1]; r.p2 = px[src * 3 + 2];
+    r.c0 = c[0]; r.c1 = c[1]; r.c2 = c[2];
   };
-  auto put_x = [&](int buf, const f32x4 &v) {
+  auto put_x = [&](int buf, const RawRow &r) {
     if (tid < TP) {
       float *x = bufX + buf * TP * XS0 + tid * XS0;
-      *reinterpret_cast<f32x4 *>(x) = v;
+      // pointnet2_utils.py:346-348
+      *reinterpret_cast<f32x4 *>(x) = f32x4{(r.p0 - r.c0) / radius, (r.p1 - r.c1) / radius, (r.p2 - r.c2) / radius, 0.f};
       *reinterpret_cast<f32x4 *>(x + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
@@ -754,7 +776,7 @@ __global__ __launch_bounds__(NWV * 64) void sa_hoist_split_kernel(const float *_
   f32x4 pf[MTW][4];
   int ixn[MTW], sxn;
   {
-    f32x4 v;
+    RawRow v;
     fetch_i(tile, ixn, sxn);
     fetch_p(tile, ixn, pf);
     fetch_x(tile, sxn, v);
@@ -772,14 +794,17 @@ __global__ __launch_bounds__(NWV * 64) void sa_hoist_split_kernel(const float *_
     const int g0 = tile * GPT;
     const bool has_next = tile + 1 < tile_end;
     GN_PROBE(0);
-    f32x4 nv;
-    if (has_next) {     // rows of the next tile (their indices arrived during the previous tile), then the indices after
+    RawRow nv;
+    GN_PROBE(1);
+    __syncthreads();                      // layer 1 of this tile (done under the previous tile's layer 3) is published
+    // rows of the next tile (their indices arrived during the previous tile), then the indices after: requested behind the
+    // barrier rather than at the loop top, where the vmcnt(0) in front of their address arithmetic also waited for the
+    // write acknowledgement of the pooled rows stored a few instructions earlier (see the SA1 kernel)
+    if (has_next) {
       fetch_p(tile + 1, ixn, pf);
       fetch_x(tile + 1, sxn, nv);
       if (tile + 2 < tile_end) fetch_i(tile + 2, ixn, sxn);
     }
-    GN_PROBE(1);
-    __syncthreads();                      // layer 1 of this tile (done under the previous tile's layer 3) is published
     GN_PROBE(2);
     StoreSplit e2{bufY2, sp_stride(C2), P2, lane};
     run_layer_split_t_pipe<TP, C1, C2, NWV>(w2, b2t, bufY1, P1, wave, lane, e2);

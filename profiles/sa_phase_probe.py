@@ -30,3 +30,6 @@ v = [sum(buf[w * 16 + i] for w in range(4)) for i in range(16)]
 tiles = v[9] / 4.0
 print("tiles %d; cycles per 64-row tile (avg over waves): " % tiles + "  ".join("%s %.0f" % (names[i], v[i] / max(v[9], 1)) for i in range(6)),
       " total %.0f" % (sum(v[:6]) / max(v[9], 1)))
+for w in range(4):
+    vw = [buf[w * 16 + i] for i in range(16)]
+    print("  wave %d: " % w + "  ".join("%s %.0f" % (names[i], vw[i] / max(vw[9], 1)) for i in range(6)))

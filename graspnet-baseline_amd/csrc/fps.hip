@@ -112,7 +112,34 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
   if (t < 3) s_key[t] = 0ULL;
   __syncthreads();
 
-  for (int j = 1; j < m; ++j) {
+  // Warm start behind a tie: the producing call met its first tie between distinct points at step T = prefix_ok[b] < m.
+  // Steps below T are still the identity prefix (a unique maximum is the same point in any tie order), so samples
+  // 0 .. T-1 are written at once and the running distances after them are rebuilt WITHOUT the arg-max chain -- one
+  // distance update per (point, sample), no reduction, no barrier, ~4x cheaper per step -- and the chain proper starts
+  // at step T.  min() is exact in any order: the state equals what T - 1 chain iterations would have left.
+  int j0 = 1;
+  if (LDSXYZ && prefix_ok && m <= n) {
+    const int T = min(prefix_ok[blockIdx.x], m);
+    if (T >= 2) {
+      for (int j = 1 + t; j < T; j += NT) {
+        idx[j] = j;
+        if (new_xyz) { new_xyz[j * 3 + 0] = lds_xyz[j * 3 + 0]; new_xyz[j * 3 + 1] = lds_xyz[j * 3 + 1]; new_xyz[j * 3 + 2] = lds_xyz[j * 3 + 2]; }
+      }
+      for (int jj = 0; jj + 1 < T; ++jj) {          // sample jj's update belongs to chain iteration jj + 1
+        const float sx = lds_xyz[jj * 3 + 0], sy = lds_xyz[jj * 3 + 1], sz = lds_xyz[jj * 3 + 2];
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+          const float dx = px[s] - sx, dy = py[s] - sy, dz = pz[s] - sz;
+          const float d = dx * dx + dy * dy + dz * dz;
+          tmp[s] = vmin(d, tmp[s]);
+        }
+      }
+      x1 = lds_xyz[(T - 1) * 3 + 0]; y1 = lds_xyz[(T - 1) * 3 + 1]; z1 = lds_xyz[(T - 1) * 3 + 2];
+      j0 = T;
+    }
+  }
+
+  for (int j = j0; j < m; ++j) {
     float best = -1.0f;
     int bslot = 0;
 #pragma unroll

@@ -119,6 +119,38 @@ def test_fps_tie_step_is_exact(variant, seed):
         assert min(want) == 0x7fffffff
 
 
+def test_fps_warm_start_behind_a_tie(oracle):
+    """the deeper samplers behind SA1's tie report: steps below the reported step are written as the identity prefix, the
+    running distances rebuilt without the arg-max chain, the chain run from there.  Uniform scenes 1024.. hold ties at
+    steps 195 / 1262 / 1779 (scenes 0, 3, 5); any smaller report must give the same samples too."""
+    from graspnet_amd import _lib as L
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    x = _cloud(1024, 8, 20000, "uniform")
+    xd = x.cuda()
+    ws = torch.empty(max(int(lib.gn_fps_workspace_bytes(8, 20000)), 16), dtype=torch.uint8, device="cuda")
+    idx1 = torch.empty(8, 2048, dtype=torch.int32, device="cuda")
+    xyz1 = torch.empty(8, 2048, 3, device="cuda")
+    tie = torch.empty(8, dtype=torch.int32, device="cuda")
+    L.check(lib.gn_furthest_point_sampling(xd.data_ptr(), 8, 20000, 2048, ws.data_ptr(), idx1.data_ptr(), xyz1.data_ptr(),
+                                           tie.data_ptr(), None, st), "fps1")
+    torch.cuda.synchronize()
+    assert tie.cpu().tolist()[0] == 195
+    level = xyz1
+    for n, m in ((2048, 1024), (1024, 512), (512, 256)):
+        want = oracle.furthest_point_sampling(level.cpu(), m)
+        outs = []
+        for flag in (tie, torch.clamp(tie, max=100), torch.clamp(tie, max=2), torch.zeros_like(tie)):
+            idx = torch.full((8, m), -1, dtype=torch.int32, device="cuda")
+            nx = torch.full((8, m, 3), float("nan"), device="cuda")
+            L.check(lib.gn_furthest_point_sampling(level.data_ptr(), 8, n, m, None, idx.data_ptr(), nx.data_ptr(), None,
+                                                   flag.data_ptr(), st), "fps deeper")
+            torch.cuda.synchronize()
+            assert torch.equal(idx.cpu(), want)
+            assert torch.equal(nx, torch.gather(level, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)))
+        level = nx
+
+
 SA = [(20000, 2048, 0.04, 64), (2048, 1024, 0.1, 32), (1024, 512, 0.2, 16), (512, 256, 0.3, 16)]
 
 

@@ -125,8 +125,10 @@ __device__ __forceinline__ void load_fp_split(__bf16 *__restrict__ ys, int plane
 // bias of the 16 accumulator rows of n-tile nt (T orientation: rows = channels 8g + 4*(lane>>5) + j): four 16-byte loads,
 // issued when the layer starts and consumed by its epilogue, so their L2 round trip hides under the layer's MFMAs
 __device__ __forceinline__ void load_bias_t4(const float *__restrict__ bp, int nt, int lane, f32x4 (&bt)[4]) {
+  using gf4 = const __attribute__((address_space(1))) f32x4;     // global, not flat: see StreamChunk::load
+  const __attribute__((address_space(1))) float *gb = (const __attribute__((address_space(1))) float *)bp;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) bt[g] = *reinterpret_cast<const f32x4 *>(bp + nt * 32 + 8 * g + 4 * (lane >> 5));
+  for (int g = 0; g < 4; ++g) bt[g] = *(gf4 *)(gb + nt * 32 + 8 * g + 4 * (lane >> 5));
 }
 
 // shape of a streamed layer for this kernel family.  CHREG: registers one weight chunk may take per wave (96 with one
@@ -154,17 +156,22 @@ template <int TP, int CINP, int COUTP, int CHREG>
 struct StreamChunk {
   using C = StreamCfg<TP, CINP, COUTP, CHREG>;
   bf16x8 v[C::NTW][C::KBC][3];
+  // The weights are addressed as GLOBAL memory explicitly.  Behind the `asm` that pins a layer's pointer below its barrier
+  // the compiler no longer knows the address space and emitted flat_load -- which counts on lgkmcnt as well as vmcnt, so
+  // the first s_waitcnt lgkmcnt(0) for an LDS operand of the CURRENT chunk also waited for the NEXT chunk's weights: the
+  // double buffering never overlapped anything (58 / 75 / 91 cycles per MFMA in the heads' layers against 34 bare).
   __device__ __forceinline__ void load(const void *__restrict__ wq, int c, int wave, int lane) {
     const int wn = wave % C::WN;
-    const char *wbase = static_cast<const char *>(wq);
+    using gchar = const __attribute__((address_space(1))) char;
+    using gfrag = const __attribute__((address_space(1))) bf16x8;
+    gchar *wbase = (gchar *)wq;
 #pragma unroll
     for (int i = 0; i < C::NTW; ++i)
 #pragma unroll
       for (int kb = 0; kb < C::KBC; ++kb)
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-          v[i][kb][p] = *reinterpret_cast<const bf16x8 *>(
-              wbase + ((((size_t)((wn * C::NTW + i) * C::KB + c * C::KBC + kb)) * 3 + p) * 64 + lane) * 16);
+          v[i][kb][p] = *(gfrag *)(wbase + ((((size_t)((wn * C::NTW + i) * C::KB + c * C::KBC + kb)) * 3 + p) * 64 + lane) * 16);
   }
   // called where the chunk is consumed (its data is needed there anyway; at the load an asm operand would force the
   // wait and undo the double buffering): from here on the fragments live in AGPRs and the MFMAs read them from there
@@ -179,22 +186,41 @@ struct StreamChunk {
   }
 };
 
-// (Requesting the NEXT layer's chunk 0 while this layer finishes -- each layer otherwise starts with an L2 round trip
-// for its first chunk, ~2.5 k cycles -- keeps three layers' chunk buffers live across the tile loop and spills
-// 250-850 bytes per lane as written; left for a restructured kernel.)
+// Every layer used to start with an L2 round trip for its first weight chunk (~2.5 k cycles with nothing else to do: the
+// phase probe shows 58 / 75 / 91 cycles per MFMA in the heads' three layers against 34 bare).  The first chunk of layer
+// L+1 is now requested by layer L just before its epilogue -- its own chunk buffers are dead by then, so the registers are
+// there -- and lands under the epilogue and the barrier behind it; layer 1's is requested at the tile top, under the row
+// fetch.  (Requesting it any earlier, while layer L still streams, keeps three layers' buffers live and spills.)
 // BLOCK2: the layer is two independent halves side by side (OperationNet | ToleranceNet, modules.py:171-175,216-220, packed
 // as ONE block-diagonal matrix): output channels of the first half read only the first half of K, the others only the
 // second, and the other K chunks of a wave's weight slice are all zeros -- they are not streamed and not multiplied.
-template <int TP, int CINP, int COUTP, int XS, int CHREG, bool BLOCK2, class Retire, class Epi>
+// first chunk of a (BLOCK2) layer for this wave
+template <int TP, int CINP, int COUTP, int CHREG, bool BLOCK2>
+__device__ __forceinline__ int stream_first_chunk(int wave) {
+  using C = StreamCfg<TP, CINP, COUTP, CHREG>;
+  return BLOCK2 ? ((wave % C::WN) >= C::WN / 2 ? C::NCH / 2 : 0) : 0;
+}
+// request the first chunk of a layer (no-op for the waves the layer leaves idle)
+template <int TP, int CINP, int COUTP, int CHREG, bool BLOCK2>
+__device__ __forceinline__ void stream_prefetch(StreamChunk<TP, CINP, COUTP, CHREG> &ch, const void *__restrict__ wq, int wave, int lane) {
+  using C = StreamCfg<TP, CINP, COUTP, CHREG>;
+  if (C::NACTIVE < 4 && wave >= C::NACTIVE) return;
+  ch.load(wq, stream_first_chunk<TP, CINP, COUTP, CHREG, BLOCK2>(wave), wave, lane);
+}
+
+// `first` arrives with the layer's first chunk already requested (stream_prefetch); `pre()` requests the next layer's
+template <int TP, int CINP, int COUTP, int XS, int CHREG, bool BLOCK2, bool HAVE_FIRST, class Retire, class Epi, class Pre>
 __device__ __forceinline__ void run_layer_stream_split_t(const void *__restrict__ wq, const float *__restrict__ bias,
                                                          const __bf16 *__restrict__ xs, int xplane, int wave, int lane,
-                                                         Retire &&retire, Epi &&epi) {
+                                                         StreamChunk<TP, CINP, COUTP, CHREG> &first, Retire &&retire, Epi &&epi,
+                                                         Pre &&pre) {
   using C = StreamCfg<TP, CINP, COUTP, CHREG>;
   constexpr int WN = C::WN, NTW = C::NTW, MTW = C::MTW, KBC = C::KBC, NCH = C::NCH;
   static_assert(!BLOCK2 || (WN % 2 == 0 && NCH % 4 == 0), "halves must fall on wave and (even) chunk boundaries");
   const int wm = wave / WN, wn = wave % WN;
   asm volatile("" : "+s"(wq), "+s"(bias));   // keep this layer's own loads below the barrier that precedes it
   if (C::NACTIVE < 4 && wave >= C::NACTIVE) {   // fewer tiles than waves: the others only keep the barrier count
+    pre();
     retire();
     return;
   }
@@ -210,19 +236,25 @@ __device__ __forceinline__ void run_layer_stream_split_t(const void *__restrict_
         acc[mi][i][r] = 0.f;
         accl[mi][i][r] = 0.f;
       }
-  StreamChunk<TP, CINP, COUTP, CHREG> first, other;
+  StreamChunk<TP, CINP, COUTP, CHREG> other;
   const int c0 = BLOCK2 ? (wn >= WN / 2 ? NCH / 2 : 0) : 0, c1 = BLOCK2 ? c0 + NCH / 2 : NCH;   // c0 even: buffer parity = c & 1
-  first.load(wq, c0, wave, lane);
+  if constexpr (!HAVE_FIRST) first.load(wq, c0, wave, lane);
   f32x4 bt[NTW][4];
 #pragma unroll
   for (int i = 0; i < NTW; ++i) load_bias_t4(bias, wn * NTW + i, lane, bt[i]);
-#pragma unroll 2
-  for (int c = c0; c < c1; ++c) {
-    if (c + 1 < c1) {
-      if (c & 1) first.load(wq, c + 1, wave, lane); else other.load(wq, c + 1, wave, lane);
+  // Unrolled in full: with the two-step loop the compiler could not count the loads in flight across the loop edge and
+  // waited for vmcnt(0) before every second chunk -- i.e. for the chunk it had just requested -- so half of the
+  // double-buffered loads overlapped nothing.  Straight-line code gets the exact vmcnt(#loads of the next chunk).
+  constexpr int NCC = BLOCK2 ? NCH / 2 : NCH;
+  (void)c1;
+#pragma unroll
+  for (int cc = 0; cc < NCC; ++cc) {
+    const int c = c0 + cc;                 // c0 is even: buffer parity = cc & 1 (compile time)
+    if (cc + 1 < NCC) {
+      if (cc & 1) first.load(wq, c + 1, wave, lane); else other.load(wq, c + 1, wave, lane);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (c & 1) other.pin(); else first.pin();
+    if (cc & 1) other.pin(); else first.pin();
 #pragma unroll
     for (int mi = 0; mi < MTW; ++mi) {
       const int mt = wm * MTW + mi;
@@ -236,7 +268,7 @@ __device__ __forceinline__ void run_layer_stream_split_t(const void *__restrict_
       for (int kb = 0; kb < KBC; ++kb)
 #pragma unroll
         for (int i = 0; i < NTW; ++i)
-          if (c & 1) mfma6_2acc<true>(a[kb], other.v[i][kb], acc[mi][i], accl[mi][i]);
+          if (cc & 1) mfma6_2acc<true>(a[kb], other.v[i][kb], acc[mi][i], accl[mi][i]);
           else mfma6_2acc<true>(a[kb], first.v[i][kb], acc[mi][i], accl[mi][i]);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -247,6 +279,7 @@ __device__ __forceinline__ void run_layer_stream_split_t(const void *__restrict_
   for (int i = 0; i < NTW; ++i)
 #pragma unroll
     for (int g = 0; g < 4; ++g) asm volatile("" : "+a"(bt[i][g]));
+  pre();
   retire();
 #pragma unroll
   for (int mi = 0; mi < MTW; ++mi)
@@ -268,6 +301,9 @@ enum { PLOAD_PLAIN = 0, PLOAD_FP = 1 };
 template <int LOADER, int NL, int C0, int C1P, int C1L, int C2P, int C2L, int C3P, int TP, bool RELU_OUT, int WPC = 1, bool BD2 = false>
 __global__ __launch_bounds__(MLP_THREADS, WPC) void point_mlp_split_kernel(PointSplitArgs a, int ntiles) {
   constexpr int CHREG = WPC >= 2 ? 48 : 96;
+  // next layer's first chunk requested ahead (see run_layer_stream_split_t): not in the two-workgroup shapes (128 + 128
+  // registers: a chunk held across the row fetch or an epilogue spills ~200 registers) nor where a layer is 384 wide
+  constexpr bool PF = WPC == 1 && C2P <= 256 && C3P <= 256;
   constexpr int CMAX = cmax(C0, cmax(NL > 1 ? C1L : 0, NL > 2 ? C2L : 0));
   constexpr int XS = sp_stride(CMAX), PL = TP * XS;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -280,6 +316,8 @@ __global__ __launch_bounds__(MLP_THREADS, WPC) void point_mlp_split_kernel(Point
     GN_PROBE(7);
     const int row0 = tile * TP;
     const int nrows = min(TP, a.nrows - row0);
+    StreamChunk<TP, C0, C1P, CHREG> ch1;
+    if constexpr (PF) stream_prefetch<TP, C0, C1P, CHREG, false>(ch1, a.w[0], wave, lane);      // lands under the row fetch
     if constexpr (LOADER == PLOAD_FP) load_fp_split<C0 / 2, C0 / 2, TP, XS>(buf, PL, a, row0, tid);
     else load_plain_split<C0, TP, XS>(buf, PL, a.x, row0, a.nrows, tid);
     GN_PROBE(0);
@@ -307,21 +345,32 @@ __global__ __launch_bounds__(MLP_THREADS, WPC) void point_mlp_split_kernel(Point
           }
       }
     };
+    auto nopre = []() {};
     if constexpr (NL == 1) {
-      run_layer_stream_split_t<TP, C0, C1P, XS, CHREG, false>(a.w[0], a.b[0], buf, PL, wave, lane, none, to_global);
+      run_layer_stream_split_t<TP, C0, C1P, XS, CHREG, false, PF>(a.w[0], a.b[0], buf, PL, wave, lane, ch1, none, to_global, nopre);
     } else {
-      run_layer_stream_split_t<TP, C0, C1P, XS, CHREG, false>(a.w[0], a.b[0], buf, PL, wave, lane, barrier, to_lds(C1L));
-      GN_PROBE(2);
-      __syncthreads();
-      GN_PROBE(3);
       if constexpr (NL == 2) {
-        run_layer_stream_split_t<TP, C1L, C2P, XS, CHREG, BD2>(a.w[1], a.b[1], buf, PL, wave, lane, none, to_global);
+        StreamChunk<TP, C1L, C2P, CHREG> ch2;
+        run_layer_stream_split_t<TP, C0, C1P, XS, CHREG, false, PF>(a.w[0], a.b[0], buf, PL, wave, lane, ch1, barrier, to_lds(C1L),
+                                                               [&]() { if constexpr (PF) stream_prefetch<TP, C1L, C2P, CHREG, BD2>(ch2, a.w[1], wave, lane); });
+        GN_PROBE(2);
+        __syncthreads();
+        GN_PROBE(3);
+        run_layer_stream_split_t<TP, C1L, C2P, XS, CHREG, BD2, PF>(a.w[1], a.b[1], buf, PL, wave, lane, ch2, none, to_global, nopre);
       } else {
-        run_layer_stream_split_t<TP, C1L, C2P, XS, CHREG, BD2>(a.w[1], a.b[1], buf, PL, wave, lane, barrier, to_lds(C2L));
+        StreamChunk<TP, C1L, C2P, CHREG> ch2;
+        StreamChunk<TP, C2L, C3P, CHREG> ch3;
+        run_layer_stream_split_t<TP, C0, C1P, XS, CHREG, false, PF>(a.w[0], a.b[0], buf, PL, wave, lane, ch1, barrier, to_lds(C1L),
+                                                               [&]() { if constexpr (PF) stream_prefetch<TP, C1L, C2P, CHREG, BD2>(ch2, a.w[1], wave, lane); });
+        GN_PROBE(2);
+        __syncthreads();
+        GN_PROBE(3);
+        run_layer_stream_split_t<TP, C1L, C2P, XS, CHREG, BD2, PF>(a.w[1], a.b[1], buf, PL, wave, lane, ch2, barrier, to_lds(C2L),
+                                                             [&]() { if constexpr (PF) stream_prefetch<TP, C2L, C3P, CHREG, false>(ch3, a.w[2], wave, lane); });
         GN_PROBE(4);
         __syncthreads();
         GN_PROBE(5);
-        run_layer_stream_split_t<TP, C2L, C3P, XS, CHREG, false>(a.w[2], a.b[2], buf, PL, wave, lane, none, to_global);
+        run_layer_stream_split_t<TP, C2L, C3P, XS, CHREG, false, PF>(a.w[2], a.b[2], buf, PL, wave, lane, ch3, none, to_global, nopre);
         GN_PROBE(6);
       }
     }

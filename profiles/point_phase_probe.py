@@ -23,3 +23,6 @@ names = ["load+split", "bar", "layer1 (mfma|bar|store)", "bar", "layer2", "bar",
 v = [sum(buf[w * 16 + i] for w in range(4)) for i in range(16)]
 print("cycles per 64-row tile (avg over waves): " + "  ".join("%s %.0f" % (names[i], v[i] / max(v[9], 1)) for i in range(8)),
       " total %.0f" % (sum(v[:8]) / max(v[9], 1)))
+for w in range(4):
+    vw = [buf[w * 16 + i] for i in range(16)]
+    print("  wave %d: " % w + "  ".join("%s %.0f" % (names[i], vw[i] / max(vw[9], 1)) for i in range(8)))

@@ -126,11 +126,44 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const float *__restric
 }
 
 // ---- 64-lane sorted-set helpers (one key per lane, ascending across lanes) --------------------------
+// One compare-exchange step of the sorting networks: lane l keeps min or max of (v[l], v[l ^ partner_mask]).  The partner
+// comes through DPP, fused into the v_min / v_max, for the distances a 16-lane row can reach (1, 2: quad_perm; 8: row_ror;
+// 4: row_shl for the banks whose partner lies above, row_shr for the others) -- 15 of the 21 steps of sort64 and 4 of the
+// 6 of a merge; only distances 16 and 32 still take the LDS crossbar (ds_bpermute + a wait for its round trip, which
+// every step did before: a chain of 28 dependent LDS round trips per fold).
+#define GN_DPP_MINMAX(CTRL)                                                                                        \
+  asm volatile("s_nop 1\n\tv_min_i32_dpp %0, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                        \
+               "v_max_i32_dpp %1, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf"                                       \
+               : "=&v"(lo), "=&v"(hi)                                                                               \
+               : "v"(v))
 __device__ __forceinline__ int cmpx(int v, int partner_mask, bool keep_min, int lane) {
-  const int o = __shfl_xor(v, partner_mask);
   (void)lane;
-  return keep_min ? min(v, o) : max(v, o);
+  int lo, hi;
+  if (partner_mask == 1) {
+    GN_DPP_MINMAX("quad_perm:[1,0,3,2]");
+  } else if (partner_mask == 2) {
+    GN_DPP_MINMAX("quad_perm:[2,3,0,1]");
+  } else if (partner_mask == 8) {
+    GN_DPP_MINMAX("row_ror:8");
+  } else if (partner_mask == 4) {
+    // every lane is written by exactly one of the two masked steps.  The outputs are early-clobber registers of their
+    // own: as read-write copies of v the compiler merged them with v, and the second step then read lanes the first had
+    // just overwritten.
+    asm volatile("s_nop 1\n\t"
+                 "v_min_i32_dpp %0, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_min_i32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                 "v_max_i32_dpp %1, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_max_i32_dpp %1, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(v));
+  } else {
+    const int o = __shfl_xor(v, partner_mask);
+    lo = min(v, o);
+    hi = max(v, o);
+  }
+  return keep_min ? lo : hi;
 }
+#undef GN_DPP_MINMAX
 // full bitonic sort of 64 keys
 __device__ __forceinline__ int sort64(int v, int lane) {
 #pragma unroll

@@ -5,8 +5,8 @@ One step = one pass of the hot path over one batch: (8, 20000, 3) synthetic clou
 resident in HBM -> GraspNet.forward (4xSA, 2xFP, ApproachNet, CloudCrop, heads) -> pred_decode
 (padded (8,1024,17) grasp rows + counts on device) [-> all-gather of the grasp lists when N>1].
 
-  python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W        (N > 1: starts the N ranks itself, as child processes)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the driver's form)
 
 Rank 0 prints ONE JSON line.  `value` is the headline leg: K timed steps issued round-robin on `--streams`
 HIP streams over 4 distinct sets of 8 `uniform` clouds, nothing but the product path inside the
@@ -157,6 +157,27 @@ def op_rooflines(dev, reps=20):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Parent of an N-rank run started WITHOUT a launcher: one child `python -m torch.distributed.run` (which starts the
+    N ranks, one per GPU) on a free local port; the children's stdout (rank 0's ONE JSON line) and stderr pass straight
+    through; returns the launcher's exit status (non-zero if any rank failed).  Never an exec: a process is only
+    ever started fresh, before it has touched the GPU."""
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    log("launching %d ranks: %s" % (n, " ".join(cmd)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,6 +199,9 @@ def main():
                     help="all | headline (only the timed headline leg + the isolated per-kernel pass: what the rocprofv3 passes "
                          "run) | comma list of the legs beside the headline: single,other,f32,graph,ops,cpu")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, form the process group, print {n_gpus, ranks_seen, backend} and stop: checks the "
+                         "N-rank launch without touching a GPU (CPU tests, with --backend gloo)")
     ap.add_argument("--cpu-reps", type=int, default=10, help="timed config[0] calls of the CPU baseline (config[1]: a third)")
     args = ap.parse_args()
     all_legs = {"single", "other", "f32", "graph", "ops", "cpu"}
@@ -187,10 +211,30 @@ def main():
     if args.no_cpu_baseline:
         legs.discard("cpu")
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: this process has made no GPU call yet (importing torch does not
+        # initialise HIP), so it only launches the N ranks as CHILD processes and relays rank 0's JSON line
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; start it as `python bench.py --gpus N` "
+                         "(it launches the ranks itself) or under torch.distributed.run with --nproc-per-node equal to --gpus"
+                         % (args.gpus, world))
     import torch.distributed as dist
+    if args.rendezvous_only:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        dist.init_process_group(args.backend if args.backend != "nccl" or torch.cuda.is_available() else "gloo",
+                                rank=rank, world_size=world)
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, local))
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                              "ranks": sorted(r for r, _ in seen), "rendezvous_only": True}))
+        dist.destroy_process_group()
+        return
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         local = local % max(torch.cuda.device_count(), 1)
@@ -227,6 +271,7 @@ def main():
     sets = cloud_sets(args.variant)
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
     gatherer = gdist.GraspGatherer(dev) if world > 1 else None
+    rank_devices = [dev.index]
 
     def run_steps(model, batches, strms, nsteps, gather=True):
         last = None
@@ -256,10 +301,11 @@ def main():
         elapsed = time.perf_counter() - t0
         per_rank = [elapsed]
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed, float(dev.index)], dtype=torch.float64, device=dev)
             allt = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(allt, t)
-            per_rank = [float(x.item()) for x in allt]
+            per_rank = [float(x[0].item()) for x in allt]
+            rank_devices[:] = [int(x[1].item()) for x in allt]
             elapsed = max(per_rank)
         return elapsed, per_rank, last
 
@@ -387,7 +433,9 @@ def main():
         out = {
             "metric": "scenes/s grasp inference, 20k-pt clouds, batch 8",
             "value": world * B * args.steps / elapsed, "unit": "scenes/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "ranks_seen": dist.get_world_size() if world > 1 else 1,
+            "backend": (dist.get_backend() if world > 1 else None), "rank_devices": rank_devices,
+            "visible_devices": torch.cuda.device_count(), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
             "vs_baseline": None,
             "dtype": ("f32 (grouped layers: exact 3xbf16 operand split, 6 bf16 MFMA products per MAC, fp32 accumulate)"

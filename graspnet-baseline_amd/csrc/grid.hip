@@ -26,8 +26,15 @@ struct GridHeader {
 };
 
 __device__ __forceinline__ int cell_coord(float v, float mn, float inv, int dim) {
-  const int c = (int)((v - mn) * inv);
-  return c < 0 ? 0 : (c >= dim ? dim - 1 : c);
+  const float f = (v - mn) * inv;                 // NaN -> cell 0, +-Inf / huge -> an edge cell (compared in float:
+  return !(f >= 1.f) ? 0 : (f >= (float)dim ? dim - 1 : (int)f);   // the int conversion never sees a value out of range)
+}
+
+// a centre's cell from its UNCLAMPED coordinate (it may lie outside the cloud's box); a far or non-finite centre lands
+// 2^20 cells outside, where its window is empty (as its hit list is), without leaving the range of int arithmetic
+__device__ __forceinline__ int centre_cell(float v, float mn, float inv) {
+  const float f = floorf((v - mn) * inv);
+  return !(f > -1048576.f) ? -1048576 : (f < 1048576.f ? (int)f : 1048576);
 }
 
 // one workgroup per cloud: extent -> cell histogram (LDS) -> exclusive scan -> ticket scatter.
@@ -47,11 +54,15 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const float *__restric
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  // the box of the FINITE coordinates: an Inf / NaN coordinate can never be a hit (every predicate on it is false, as in
+  // the reference's scan), so it must not stretch the grid either; cell_coord clamps such a point into an edge cell
   for (int k = t; k < n; k += 1024)
     for (int a = 0; a < 3; ++a) {
       const float v = xyz[k * 3 + a];
-      mn[a] = fminf(mn[a], v);
-      mx[a] = fmaxf(mx[a], v);
+      if (fabsf(v) < INFINITY) {
+        mn[a] = fminf(mn[a], v);
+        mx[a] = fmaxf(mx[a], v);
+      }
     }
   for (int a = 0; a < 3; ++a) {
     const float lo = -wave_max(-mn[a]), hi = wave_max(mx[a]);
@@ -71,10 +82,13 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const float *__restric
   float inv[3];
   const int cap[3] = {GRID_MAX_DIM, GRID_MAX_DIM, GRID_MAX_DIMZ};
   for (int a = 0; a < 3; ++a) {
-    const float ext = fmaxf(mx[a] - mn[a], 0.f);
-    int d = (int)(ext / h) + 1;
+    if (!(mn[a] <= mx[a])) mn[a] = mx[a] = 0.f;               // no finite coordinate on this axis
+    const float ext = fminf(fmaxf(mx[a] - mn[a], 0.f), 3.0e38f);
+    // cells this axis would need, compared in float: (int)(ext / h) + 1 overflows for a far outlier (ext / h >= 2^31)
+    const float need = ext / h;
+    int d = need < (float)cap[a] ? (int)need + 1 : cap[a] + 1;
     float cs = h;
-    if (d > cap[a]) { d = cap[a]; cs = ext / (float)cap[a] * 1.001f; }
+    if (d > cap[a]) { d = cap[a]; cs = fmaxf(ext / (float)cap[a] * 1.001f, h); }
     dim[a] = d;
     inv[a] = 1.0f / cs;
   }
@@ -187,6 +201,22 @@ __device__ __forceinline__ int merge_low64(int a, int b, int lane) {
 
 constexpr int GQ_WAVES = 4;
 
+// The cylinder kernels' cell windows assume that `rot` is a rotation: then |p - c| = |R^T (p - c)| < sqrt(radius^2 + h^2)
+// and the first column is the cylinder's unit axis.  cylinder_query_gpu.cu:39-47 takes ANY 3x3, so each seed tests
+// max |R^T R - I| on the device; a seed that fails (scaled / sheared / NaN matrix) walks every cell of the grid -- the
+// sorted-set bookkeeping does not care where candidates come from, so its list is still the reference's.  2e-5 keeps the
+// length error (<= 3e-5 relative) inside the windows' own margins (reach x 1.0001, cells x 1.001, box x 1.002); float
+// rotation matrices from batch_viewpoint_params_to_matrix sit at ~1e-7.
+__device__ __forceinline__ bool rot_is_orthonormal(float r0, float r1, float r2, float r3, float r4, float r5, float r6,
+                                                   float r7, float r8) {
+  const float g00 = r0 * r0 + r3 * r3 + r6 * r6 - 1.f, g11 = r1 * r1 + r4 * r4 + r7 * r7 - 1.f,
+              g22 = r2 * r2 + r5 * r5 + r8 * r8 - 1.f;
+  const float g01 = r0 * r1 + r3 * r4 + r6 * r7, g02 = r0 * r2 + r3 * r5 + r6 * r8, g12 = r1 * r2 + r4 * r5 + r7 * r8;
+  const float e = fmaxf(fmaxf(fmaxf(fabsf(g00), fabsf(g11)), fmaxf(fabsf(g22), fabsf(g01))), fmaxf(fabsf(g02), fabsf(g12)));
+  return e <= 2e-5f && fabsf(g00) <= 2e-5f && fabsf(g11) <= 2e-5f && fabsf(g22) <= 2e-5f && fabsf(g01) <= 2e-5f &&
+         fabsf(g02) <= 2e-5f && fabsf(g12) <= 2e-5f;      // the second form is false for NaN whatever fmaxf returns
+}
+
 // Cell window [lo, hi] per axis that contains every point of the cylinder { p : hmin < a.(p-c) < hmax, |p-c - (a.(p-c))a| < radius }:
 // its axis-aligned bounding box is centre c + a(hmin+hmax)/2, half-extent |a_i|(hmax-hmin)/2 + radius*sqrt(1-a_i^2) per axis
 // (taken 0.2 % + 1e-6 wider: a is a float rotation column).  cell_coord is the monotone map the build kernel bins with, so a
@@ -239,8 +269,7 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void ball_grid_kernel(const float *_
     r0 = r[0]; r1 = r[1]; r2 = r[2]; r3 = r[3]; r4 = r[4]; r5 = r[5]; r6 = r[6]; r7 = r[7]; r8 = r[8];
   }
   // centre's cell from UNCLAMPED coordinates (a centre may lie outside the cloud's box)
-  const int ccx = (int)floorf((cx - H.minx) * H.invx), ccy = (int)floorf((cy - H.miny) * H.invy),
-            ccz = (int)floorf((cz - H.minz) * H.invz);
+  const int ccx = centre_cell(cx, H.minx, H.invx), ccy = centre_cell(cy, H.miny, H.invy), ccz = centre_cell(cz, H.minz, H.invz);
   // cell window: cells are at least 1.001 x the build reach wide; a grid built for a smaller reach just
   // widens the window
   const int rx = (int)(reach * H.invx) + 1, ry = (int)(reach * H.invy) + 1, rz = (int)(reach * H.invz) + 1;
@@ -249,6 +278,9 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void ball_grid_kernel(const float *_
   if (CYL) {      // the oriented cylinder's own bounding box instead of its bounding sphere's cube
     const CellWindow w = cylinder_window(H, cx, cy, cz, r0, r3, r6, radius, hmin, hmax);
     x0 = max(x0, w.x0); x1 = min(x1, w.x1); y0 = max(y0, w.y0); y1 = min(y1, w.y1); z0 = max(z0, w.z0); z1 = min(z1, w.z1);
+    if (!rot_is_orthonormal(r0, r1, r2, r3, r4, r5, r6, r7, r8)) {   // not a rotation: no window is safe, walk every cell
+      x0 = 0; x1 = H.dx - 1; y0 = 0; y1 = H.dy - 1; z0 = 0; z1 = H.dz - 1;
+    }
   }
   int *queue = s_queue[wv];
   int best = 0x7fffffff;    // ascending across lanes: the nsample... 64 smallest hit indices so far
@@ -344,14 +376,16 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void cylinder_unique_grid_kernel(
   const float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7], r8 = r[8];
   const float radius2 = radius * radius;
   const float hmax[4] = {hmax0, hmax1, hmax2, hmax3};
-  const int ccx = (int)floorf((cx - H.minx) * H.invx), ccy = (int)floorf((cy - H.miny) * H.invy),
-            ccz = (int)floorf((cz - H.minz) * H.invz);
+  const int ccx = centre_cell(cx, H.minx, H.invx), ccy = centre_cell(cy, H.miny, H.invy), ccz = centre_cell(cz, H.minz, H.invz);
   const int rx = (int)(reach * H.invx) + 1, ry = (int)(reach * H.invy) + 1, rz = (int)(reach * H.invz) + 1;
   // the bounding sphere's cube, cut down to the bounding box of the deepest (= largest) of the nested cylinders
   const CellWindow cw = cylinder_window(H, cx, cy, cz, r0, r3, r6, radius, hmin, hmax[ND - 1]);
-  const int x0 = max(max(ccx - rx, 0), cw.x0), x1 = min(min(ccx + rx, H.dx - 1), cw.x1);
-  const int y0 = max(max(ccy - ry, 0), cw.y0), y1 = min(min(ccy + ry, H.dy - 1), cw.y1);
-  const int z0 = max(max(ccz - rz, 0), cw.z0), z1 = min(min(ccz + rz, H.dz - 1), cw.z1);
+  int x0 = max(max(ccx - rx, 0), cw.x0), x1 = min(min(ccx + rx, H.dx - 1), cw.x1);
+  int y0 = max(max(ccy - ry, 0), cw.y0), y1 = min(min(ccy + ry, H.dy - 1), cw.y1);
+  int z0 = max(max(ccz - rz, 0), cw.z0), z1 = min(min(ccz + rz, H.dz - 1), cw.z1);
+  if (!rot_is_orthonormal(r0, r1, r2, r3, r4, r5, r6, r7, r8)) {     // not a rotation: walk every cell
+    x0 = 0; x1 = H.dx - 1; y0 = 0; y1 = H.dy - 1; z0 = 0; z1 = H.dz - 1;
+  }
   int best[ND], qn[ND], total[ND];
 #pragma unroll
   for (int d = 0; d < ND; ++d) { best[d] = 0x7fffffff; qn[d] = 0; total[d] = 0; }

@@ -35,14 +35,40 @@ def all_gather_grasps(grasps, counts, group=None):
     return recv[:, :m * w].unflatten(1, (m, w)), recv[:, m * w].view(torch.int32)
 
 
+class GatherHandle:
+    """Completion handle of one side-stream all-gather: `wait()` makes the caller's CURRENT stream depend on the collective
+    and registers the gathered buffer with that stream (it was allocated on the gatherer's side stream: without the
+    registration the caching allocator could hand the block to the next gather while a consumer kernel on another stream
+    is still reading it); `synchronize()` blocks the host instead.  `event` is the raw completion event."""
+
+    def __init__(self, event, recv):
+        self.event, self._recv = event, recv
+
+    def wait(self, stream=None):
+        cur = stream if stream is not None else torch.cuda.current_stream(self._recv.device)
+        cur.wait_event(self.event)
+        self._recv.record_stream(cur)
+        return self
+
+    def synchronize(self):
+        self.event.synchronize()
+        self._recv.record_stream(torch.cuda.current_stream(self._recv.device))
+        return self
+
+    def query(self):
+        return self.event.query()
+
+
 class GraspGatherer:
     """The all-gather of SURVEY.md 8e as specified there: on a SIDE stream, overlapped with the next batch's kernels.
 
     gather() packs the rank's padded lists on the caller's current stream, records an event, and issues the collective on
     the gatherer's own stream behind that event; the caller's stream is never blocked by the collective and goes straight
     on to its next batch (FPS of the next batch runs while RCCL moves 557 KB per rank over xGMI).  Returns the gathered
-    views plus the event a consumer must wait on (`torch.cuda.current_stream().wait_event(done)`, or a device/stream
-    synchronize) before reading them.  CPU tensors (gloo tests) gather inline."""
+    views plus a `GatherHandle`: a consumer calls `handle.wait()` on the stream it reads them from (or
+    `handle.synchronize()` on the host) before touching them.  The gathered buffer is also registered with the stream
+    gather() was called on, so the common case -- the consumer is that same stream -- is safe after `wait()` or any
+    device synchronize.  CPU tensors (gloo tests) gather inline and return no handle."""
 
     def __init__(self, device=None, group=None):
         self.group = group
@@ -68,7 +94,8 @@ class GraspGatherer:
             done = torch.cuda.Event()
             done.record(self.side)
         send.record_stream(self.side)      # allocated on the caller's stream, last read on the side stream
-        return recv[:, :m * w].unflatten(1, (m, w)), recv[:, m * w].view(torch.int32), done
+        recv.record_stream(cur)            # allocated on the side stream, read by the caller's stream(s)
+        return recv[:, :m * w].unflatten(1, (m, w)), recv[:, m * w].view(torch.int32), GatherHandle(done, recv)
 
 
 def to_list(grasps, counts):

@@ -479,22 +479,38 @@ class PipelinedGraspNet:
 
     `result()` waits for that batch only.  ROCm maps HIP streams onto 4 hardware queues unless GPU_MAX_HW_QUEUES is set
     (16 for depth 12) BEFORE the HIP runtime initialises; with fewer queues batches share a queue and serialise.
-    Outputs of a ticket are ordinary torch tensors allocated on the ticket's stream; `wait()` makes the caller's current
-    stream depend on the batch and registers the outputs with it, after which they can be used like any other tensor."""
+    Outputs of a ticket are ordinary torch tensors allocated on the ticket's stream; `wait()` (device-side dependency) and
+    `result()` (host-side wait) both register them with the caller's current stream (`record_stream`), after which they
+    can be used -- and dropped -- like any other tensor."""
 
     class Ticket:
         def __init__(self, end_points, grasps, counts, event, stream):
             self.end_points, self.grasps, self.counts, self.event, self.stream = end_points, grasps, counts, event, stream
 
+        def _tensors(self):
+            priv = self.end_points.get("_gn") or {}
+            vals = list(self.end_points.values()) + list(priv.values())
+            return [self.grasps, self.counts] + [v for v in vals if torch.is_tensor(v) and v.is_cuda]
+
+        def _register(self, cur):
+            # the outputs were allocated on the ticket's stream: tell the caching allocator that `cur` reads them too, or
+            # a tensor dropped right after an async kernel on `cur` returns its block to the ticket stream's pool at once
+            # and the next submit() on that stream may overwrite it under the kernel
+            if cur != self.stream:
+                for t in self._tensors():
+                    t.record_stream(cur)
+
         def wait(self):
+            """make the caller's current stream depend on this batch (no host sync)"""
             cur = torch.cuda.current_stream(self.grasps.device)
             cur.wait_event(self.event)
-            for t in [self.grasps, self.counts] + [v for v in self.end_points.values() if torch.is_tensor(v)]:
-                t.record_stream(cur)
+            self._register(cur)
             return self
 
         def result(self):
+            """block the host until this batch is done; the outputs are then safe to use on the current stream"""
             self.event.synchronize()
+            self._register(torch.cuda.current_stream(self.grasps.device))
             return self.end_points, self.grasps, self.counts
 
     def __init__(self, net, depth=12):

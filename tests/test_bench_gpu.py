@@ -70,3 +70,28 @@ def test_bench_strong_scaling_two_ranks_over_gloo():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["batch_per_gpu"] == 8
     assert abs(d["value"] - 16 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
     assert 16 * 300 < d["grasps_last_step"] < 16 * 1024
+
+
+def _self_launch(extra):
+    """`python bench.py --gpus 2 ...` with NO launcher in front: bench.py starts its two ranks itself"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "6",
+                          "--warmup", "4"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "launching 2 ranks" in out.stderr
+    return _last_json(out.stdout)
+
+
+def test_bench_gpus_2_starts_its_own_ranks_weak():
+    d = _self_launch([])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] == "gloo" and d["scaling"] == "weak"
+    assert len(d["rank_devices"]) == 2 and all(0 <= i < d["visible_devices"] for i in d["rank_devices"])
+    assert abs(d["value"] - 2 * 8 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
+    assert 16 * 300 < d["grasps_last_step"] < 16 * 1024
+
+
+def test_bench_gpus_2_starts_its_own_ranks_strong():
+    d = _self_launch(["--global-batch", "16"])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "strong" and d["config"]["batch_per_gpu"] == 8
+    assert abs(d["value"] - 16 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]

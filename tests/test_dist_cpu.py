@@ -68,3 +68,40 @@ def test_all_gather_grasps_gloo_world2():
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert sorted(r for _, _, r in res) == [(0, 3), (3, 6)]
+
+
+def _bench(argv, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, cwd=root, capture_output=True, text=True,
+                          timeout=600, env=env)
+
+
+def test_bench_gpus_n_launches_n_ranks_by_itself():
+    """`python bench.py --gpus 3` with no launcher in front starts three ranks as child processes (no GPU call in the
+    parent) and relays rank 0's one JSON line; --rendezvous-only stops after the process group has formed"""
+    import json
+    out = _bench(["--gpus", "3", "--backend", "gloo", "--rendezvous-only"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "launching 3 ranks" in out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["ranks_seen"] == 3 and d["ranks"] == [0, 1, 2] and d["backend"] == "gloo"
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    out = _bench(["--gpus", "4", "--rendezvous-only"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert out.returncode != 0 and "--gpus 4" in out.stderr and "WORLD_SIZE=1" in out.stderr
+
+
+def test_bench_parent_exits_nonzero_when_a_rank_fails():
+    """no GPU in the build container: the ranks of a real run die at their first device call and the parent says so"""
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a box without a GPU")
+    out = _bench(["--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0"])
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -460,6 +460,34 @@ def test_pipelined_batches_equal_one_at_a_time(net):
     assert torch.equal(t.grasps + 0, want[0][1])
 
 
+def test_pipelined_results_consumed_asynchronously_while_more_batches_are_submitted(net):
+    """result() outputs read by async kernels on the caller's stream and dropped at once, with further batches submitted on
+    the same ticket streams right behind: result() registers the outputs with the caller's stream (record_stream), so the
+    allocator cannot hand their blocks to the next submit() while the caller's kernels still read them"""
+    from graspnet_amd import PipelinedGraspNet, synthetic as S
+    batches = [S.make_batch(700 + i, 2, 5000, "uniform").cuda() for i in range(4)]
+    want = []
+    for x in batches:
+        ep = net({"point_clouds": x})
+        g, c = net.decode_padded(ep)
+        want.append((float(g.double().sum()), float(ep["view_score"].double().sum()), int(c.sum())))
+    torch.cuda.synchronize()
+    pipe = PipelinedGraspNet(net, depth=2)
+    busy = torch.empty(1 << 26, device="cuda")
+    sums = []
+    inflight = [pipe.submit(batches[i % 4]) for i in range(2)]
+    for i in range(2, 14):
+        ep, g, c = inflight.pop(0).result()
+        busy.normal_()                                # keeps the caller's stream behind, so the reads below run late
+        sums.append((g.double().sum(), ep["view_score"].double().sum(), c.sum()))
+        del ep, g, c                                  # blocks go back to the allocator while the reads are queued
+        inflight.append(pipe.submit(batches[i % 4]))
+    torch.cuda.synchronize()
+    for i, (a, b, c) in enumerate(sums):
+        w = want[i % 4]
+        assert (float(a), float(b), int(c)) == w, i
+
+
 @pytest.mark.parametrize("B,N,variant", [(1, 3000, "uniform"), (3, 4096, "surface"), (2, 9000, "uniform"),
                                          (1, 12289, "surface"), (2, 16384, "uniform"), (1, 24000, "uniform"),
                                          (1, 30000, "surface")])
@@ -474,7 +502,10 @@ def test_other_batch_and_cloud_sizes(net, model_oracle, state_dict, B, N, varian
     pr = pred_decode(ep)
     for k in ("sa1_inds", "sa2_inds", "fp2_inds", "sa1_xyz", "sa2_xyz", "sa3_xyz", "sa4_xyz"):
         assert torch.equal(ep[k].cpu(), rep[k]), k
-    PU.assert_parity("other sizes: B=%d N=%d %s" % (B, N, variant), ep, pr, rep, rp, math=MATH)
+    # float64 truth here too: THE RULE's norm-relative limit sits 5-60x above what is measured, the yardstick (error vs
+    # float64 no larger than the oracle's own) is the assertion that binds
+    tru = model_oracle.forward({"point_clouds": cl.clone()}, state_dict, f64=True, force_top_view_inds=rep["grasp_top_view_inds"])
+    PU.assert_parity("other sizes: B=%d N=%d %s" % (B, N, variant), ep, pr, rep, rp, tru, model_oracle.pred_decode(tru), MATH)
 
 
 def test_refuses_cpu_and_training(state_dict):

@@ -220,6 +220,95 @@ def test_drop_in_queries_grid_equals_scan(E, model_oracle, monkeypatch):
     assert not grid_b[0][0, :5].any() and not grid_c[1][0, :5].any()
 
 
+def test_cylinder_query_any_3x3_matrix(E, oracle, model_oracle):
+    """cylinder_query_gpu.cu:39-47 takes ANY 3x3 `rot`; the grid kernels' cell windows assume a rotation, so each seed
+    checks R^T R = I on the device and walks every cell when it fails: sheared, scaled (shrinking AND stretching),
+    reflected, singular and NaN matrices give the oracle's lists at a size (N >= 4096) that takes the grid path"""
+    n, m = 9000, 256
+    x = _cloud(611, 2, n, "surface")
+    c = x[:, ::7][:, :m].contiguous()
+    rng = np.random.default_rng(5)
+    rot = model_oracle.viewpoint_to_matrix(torch.from_numpy(rng.standard_normal((2 * m, 3)).astype(np.float32)),
+                                           torch.zeros(2 * m)).view(2, m, 3, 3).clone()
+    shear = torch.eye(3)
+    shear[0, 1] = 0.7
+    shear[2, 0] = -0.4
+    rot[:, 0:40] = rot[:, 0:40] @ shear                      # sheared
+    rot[:, 40:80] *= 0.25                                    # shrinks distances: hits far outside the nominal reach
+    rot[:, 80:120] *= 3.0                                    # stretches
+    rot[:, 120:140, :, 0] *= -1.0                            # reflection (still orthonormal: takes the window)
+    rot[:, 140:150] = 0.0                                    # singular: x_rot = 0 for every point
+    rot[0, 150:155] = float("nan")
+    rot[:, 155:175] = rot[:, 155:175] * (1.0 + 1e-4)         # just outside the orthonormality tolerance
+    rot[:, 175:195] = rot[:, 175:195] * (1.0 + 4e-6)         # inside it
+    rot = rot.reshape(2, m, 9).contiguous()
+    for hmin, hmax, ns in ((-0.02, 0.04, 64), (-0.02, 0.01, 16)):
+        want = oracle.cylinder_query(c, x, rot, 0.05, hmin, hmax, ns)
+        got = E.cylinder_query(_dev(c), _dev(x), _dev(rot), 0.05, hmin, hmax, ns).cpu()
+        assert torch.equal(got, want)
+        assert want[:, 40:80].ne(want[:, 40:80, :1]).any()      # the shrunk cylinders really do collect hits
+
+
+def test_cylinder_unique_grid_any_3x3_matrix(model_oracle):
+    """the same for CloudCrop's four nested cylinders on the grid (gn_cylinder_query_unique_grid) against the scan form"""
+    from graspnet_amd import _lib as L
+    lib = L.lib()
+    import ctypes
+    n, m = 8000, 128
+    x = _cloud(612, 2, n, "uniform").cuda()
+    c = x[:, :m].contiguous()
+    rng = np.random.default_rng(6)
+    rot = model_oracle.viewpoint_to_matrix(torch.from_numpy(rng.standard_normal((2 * m, 3)).astype(np.float32)),
+                                           torch.zeros(2 * m)).view(2, m, 3, 3).clone()
+    rot[:, 0:30] *= 0.3
+    rot[:, 30:60, 0, 1] += 0.5
+    rot[1, 60:64] = float("nan")
+    rot = rot.reshape(2, m, 9).contiguous().cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    hmax = (ctypes.c_float * 4)(0.01, 0.02, 0.03, 0.04)
+    ws = torch.empty((lib.gn_grid_workspace_bytes(2, n),), dtype=torch.uint8, device="cuda")
+    L.check(lib.gn_grid_build(x.data_ptr(), 2, n, 0.04, ws.data_ptr(), st), "grid_build")
+    ug = torch.zeros((2, m, 256), dtype=torch.int32, device="cuda")
+    cg = torch.zeros((2, m), dtype=torch.int32, device="cuda")
+    us, cs = torch.zeros_like(ug), torch.zeros_like(cg)
+    L.check(lib.gn_cylinder_query_unique_grid(c.data_ptr(), rot.data_ptr(), ws.data_ptr(), 2, n, m, 0.05, -0.02, hmax, 4, 64,
+                                              ug.data_ptr(), cg.data_ptr(), st), "unique_grid")
+    L.check(lib.gn_cylinder_query_unique(c.data_ptr(), x.data_ptr(), rot.data_ptr(), 2, n, m, 0.05, -0.02, hmax, 4, 64,
+                                         us.data_ptr(), cs.data_ptr(), st), "unique")
+    assert torch.equal(cg, cs)
+    ug, us, cnt = ug.cpu(), us.cpu(), cs.cpu()
+    for b in range(2):
+        for j in range(m):
+            k = int(cnt[b, j])
+            assert sorted(ug[b, j, :k].tolist()) == sorted(us[b, j, :k].tolist()), (b, j)   # grid: grouped by depth class
+
+
+@pytest.mark.parametrize("bad", [float("inf"), -float("inf"), float("nan"), 1e30, -3e38])
+def test_queries_with_non_finite_and_far_points(E, oracle, model_oracle, monkeypatch, bad):
+    """an Inf / NaN / 1e30 coordinate in a cloud that takes the grid path (N >= 4096): the reference's scan simply never
+    hits such a point; the grid is built over the finite box (cells counted in float, no int overflow) and returns the
+    same lists as the oracle and as the index-order scan kernels"""
+    n, m = 6000, 300
+    x = _cloud(613, 2, n, "uniform")
+    x[0, 17, 0] = bad
+    x[0, 4000, 2] = bad
+    x[1, 0] = bad
+    x[1, 5999, 1] = -bad
+    c = x[:, 100:100 + m].contiguous()
+    c[0, 3] = bad                                            # a centre out there as well: zero row
+    rng = np.random.default_rng(8)
+    rot = model_oracle.viewpoint_to_matrix(torch.from_numpy(rng.standard_normal((2 * m, 3)).astype(np.float32)),
+                                           torch.zeros(2 * m)).view(2, m, 9).contiguous()
+    wb = oracle.ball_query(c, x, 0.06, 32)
+    wc = oracle.cylinder_query(c, x, rot, 0.05, -0.02, 0.04, 64)
+    gb = E.ball_query(_dev(c), _dev(x), 0.06, 32)
+    gc = E.cylinder_query(_dev(c), _dev(x), _dev(rot), 0.05, -0.02, 0.04, 64)
+    assert torch.equal(gb.cpu(), wb) and torch.equal(gc.cpu(), wc)
+    monkeypatch.setenv("GN_QUERY_PATH", "brute")
+    assert torch.equal(E.ball_query(_dev(c), _dev(x), 0.06, 32), gb)
+    assert torch.equal(E.cylinder_query(_dev(c), _dev(x), _dev(rot), 0.05, -0.02, 0.04, 64), gc)
+
+
 def test_group_gather_bit_exact(E, oracle):
     g = torch.Generator().manual_seed(3)
     # vectorised global gathers (C=3, long rows) / LDS-staged rows with 8, 16, 16 (odd n, partial last group) and 2 channels

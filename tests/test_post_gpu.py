@@ -151,8 +151,23 @@ def test_example_scene_config5(golden_dir, state_dict):
     top = out[0, :min(50, int(oc[0]))].cpu().numpy()
     wt = z["top50"]
     assert abs(len(top) - len(wt)) <= 2 and len(top) >= 40
-    # same grasps in the same order up to near-tie score swaps: compare as sets of centres, and the score profile
-    tk, wk = {key(r) for r in top}, {key(r) for r in wt}
-    assert len(tk & wk) >= 0.9 * len(wk)
-    m = min(len(top), len(wt))
-    np.testing.assert_allclose(top[:m, 0], wt[:m, 0], rtol=2e-3, atol=3e-4)
+    # decoded rows matched by seed under THE RULE (tests/parity_util.py), discrete flips counted and bounded
+    import parity_util as PU
+    rows = PU.compare_rows([g[0, :n]], [torch.from_numpy(want)])
+    assert rows["score_max"] <= rows["score_limit"] and rows["width_max"] <= 1e-5, rows
+    assert rows["class_flips"] <= 2 and rows["objectness_flips"] <= 2 and rows["rows"] >= len(want) - 4, rows
+    # the top 50 after collision filter + NMS + sort: the same grasps (matched by seed centre, rotation and depth), each
+    # score under THE RULE; a grasp may enter / leave the list only through a near-tie (counted, at most 2), and the
+    # order may differ only between grasps whose golden scores lie within two limits of each other
+    lim = rows["score_limit"]
+    tmap, wmap50 = {key(r): r for r in top}, {key(r): r for r in wt}
+    both = [k for k in tmap if k in wmap50]
+    assert len(set(tmap) ^ set(wmap50)) <= 2, (len(tmap), len(wmap50), len(both))
+    for k in both:
+        a, b = tmap[k], wmap50[k]
+        assert np.allclose(a[3:13], b[3:13], atol=1e-5) and abs(float(a[0]) - float(b[0])) <= lim, (a[:4], b[:4])
+    order = [float(wmap50[key(r)][0]) for r in top if key(r) in wmap50]       # golden scores in the HIP list's order
+    assert all(order[i] >= order[i + 1] - 2 * lim for i in range(len(order) - 1))
+    PU.REPORT["config[4]: example scene, decode -> collision -> NMS -> top 50"] = {
+        "rows": rows, "top50": {"common": len(both), "hip": len(top), "golden": len(wt), "score_limit": lim,
+                                "score_max": max(abs(float(tmap[k][0]) - float(wmap50[k][0])) for k in both)}}

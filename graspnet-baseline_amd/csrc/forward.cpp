@@ -3,10 +3,61 @@
 // Mirrors GraspNet.forward + pred_decode of the reference (models/graspnet.py:70-134; backbone.py:105-129;
 // modules.py:41-77,109-141,169-232) as a fixed sequence of this library's own stage launches.  No device
 // code here: every stage is one of the C-ABI entry points, called with the caller's stream.
+#include <stdlib.h>
+
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "gn_common.h"
 
 namespace gn {
 namespace {
+
+// ---- fork / join inside one forward ---------------------------------------------------------------------------------
+// The forward is a chain of ~25 launches, but not all of it is ONE chain: the grid build needs only the cloud, and the
+// geometry of the deeper levels (FPS 2-4, ball queries 2-4, both three_nn) needs only sampled coordinates, never features.
+// Issued on one stream they sit in front of the MLP kernels that do not depend on them (0.05 ms of grid build in front of
+// the SA1 sampler, ~0.2 ms of small-level geometry in front of SA2-4 / FP).  With a side stream per calling stream the
+// geometry runs beside SA1's ball query + MLP, event-ordered (hipEventRecord / hipStreamWaitEvent only: no host sync, no
+// allocation after the first call on a stream, and legal under hipGraph capture -- the side stream is pulled into the
+// capture by its first wait and joins back before the call returns).  Per-stage hooks (profiling) time launches on the
+// caller's stream, so a call with a hook stays on one stream; GN_FORWARD_FORK=0 does the same.
+struct ForkCtx {
+  hipStream_t side = nullptr;
+  hipEvent_t ev[8] = {};
+};
+constexpr int kForkEvents = 8;
+
+ForkCtx *fork_ctx(hipStream_t main) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, ForkCtx *> table;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_pair(dev, main);
+  auto it = table.find(key);
+  if (it != table.end()) return it->second;
+  // first call on this stream: it may already be inside a stream capture whose mode forbids resource creation
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  ForkCtx *c = new ForkCtx();
+  bool ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; ok && i < kForkEvents; ++i) ok = hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) == hipSuccess;
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  if (!ok) {
+    (void)hipGetLastError();
+    delete c;
+    c = nullptr;               // remembered: this stream runs unforked
+  }
+  table[key] = c;
+  return c;
+}
+
+bool fork_enabled() {
+  const char *e = getenv("GN_FORWARD_FORK");
+  return !(e && e[0] == '0');
+}
 
 struct SaCfg { int npoint; float radius; int nsample; int cin; int mlp[3]; };
 // models/backbone.py:30-64
@@ -121,57 +172,128 @@ extern "C" int gn_graspnet_forward(const gn_weights *wt, const float *cloud, int
   int32_t *uidx = o->crop_uidx ? o->crop_uidx : w.uidx;
   int32_t *ucount = o->crop_ucount ? o->crop_ucount : w.ucount;
 
-  // one grid over the input cloud serves SA1's ball query and CloudCrop's cylinder query
-  if (w.grid) GN_STAGE("grid_build", gn_grid_build(cloud, b, n, kSa[0].radius, w.grid, st));
-
-  // ---- 4 set-abstraction levels (backbone.py:105-121)
   static const char *const kFps[4] = {"furthest_point_sampling[1]", "furthest_point_sampling[2]",
                                       "furthest_point_sampling[3]", "furthest_point_sampling[4]"};
   static const char *const kBall[4] = {"ball_query[1]", "ball_query[2]", "ball_query[3]", "ball_query[4]"};
   static const char *const kLin[4] = {"", "point_linear[2]", "point_linear[3]", "point_linear[4]"};
   static const char *const kSaName[4] = {"sa_group_mlp_pool[1]", "sa_hoisted_mlp_pool[2]", "sa_hoisted_mlp_pool[3]",
                                          "sa_hoisted_mlp_pool[4]"};
-  const float *lv_xyz = cloud, *lv_feat = nullptr;
-  int lv_n = n;
-  for (int l = 0; l < 4; ++l) {
+  const int lv_pts[4] = {n, kSa[0].npoint, kSa[1].npoint, kSa[2].npoint};      // points a level samples from
+  const float *const lv_xyz_of[4] = {cloud, o->sa_xyz[0], o->sa_xyz[1], o->sa_xyz[2]};
+  const float *const lv_feat_of[4] = {nullptr, o->sa_features[0], o->sa_features[1], o->sa_features[2]};
+
+  // geometry of level l (coordinates only): the sampler and the ball query (backbone.py:105-121, pointnet2_modules.py:236-249).
+  // SA1's sampler records its first exact-tie step; deeper levels (FPS-ordered input) use it to return the identity
+  // prefix at once when no tie can have changed the order
+  auto sample = [&](int l, gn_stream_t s) -> int {
     const SaCfg &c = kSa[l];
-    // SA1's sampler records its first exact-tie step; deeper levels (FPS-ordered input) use it to return the
-    // identity prefix at once when no tie can have changed the order
-    GN_STAGE(kFps[l], gn_furthest_point_sampling(lv_xyz, b, lv_n, c.npoint, w.fps[l], o->sa_inds[l], o->sa_xyz[l],
-                                                 l == 0 ? w.tie_flag : nullptr, l > 0 ? w.tie_flag : nullptr, st));
+    GN_STAGE(kFps[l], gn_furthest_point_sampling(lv_xyz_of[l], b, lv_pts[l], c.npoint, w.fps[l], o->sa_inds[l], o->sa_xyz[l],
+                                                 l == 0 ? w.tie_flag : nullptr, l > 0 ? w.tie_flag : nullptr, s));
+    return GN_OK;
+  };
+  auto query = [&](int l, gn_stream_t s) -> int {
+    const SaCfg &c = kSa[l];
     if (l == 0 && w.grid)
       GN_STAGE("ball_query_grid[1]",
-               gn_ball_query_grid(o->sa_xyz[0], w.grid, b, lv_n, c.npoint, c.radius, c.nsample, w.ball_idx[0], st));
+               gn_ball_query_grid(o->sa_xyz[0], w.grid, b, lv_pts[0], c.npoint, c.radius, c.nsample, w.ball_idx[0], s));
     else
-      GN_STAGE(kBall[l], gn_ball_query(o->sa_xyz[l], lv_xyz, b, lv_n, c.npoint, c.radius, c.nsample, w.ball_idx[l], st));
+      GN_STAGE(kBall[l], gn_ball_query(o->sa_xyz[l], lv_xyz_of[l], b, lv_pts[l], c.npoint, c.radius, c.nsample, w.ball_idx[l], s));
+    return GN_OK;
+  };
+  // features of level l: (per-point layer-1 part,) grouped MLP + max-pool
+  auto features = [&](int l, gn_stream_t s) -> int {
+    const SaCfg &c = kSa[l];
     const float *const wp[3] = {wt->sa[l].w[0], wt->sa[l].w[1], wt->sa[l].w[2]};
     const float *const bp[3] = {wt->sa[l].b[0], wt->sa[l].b[1], wt->sa[l].b[2]};
     const void *const wps[3] = {wt->sa_split[l].w[0], wt->sa_split[l].w[1], wt->sa_split[l].w[2]};
     const float *const bps[3] = {wt->sa_split[l].b[0], wt->sa_split[l].b[1], wt->sa_split[l].b[2]};
     if (c.cin == 0) {
       if (wt->use_split)
-        GN_STAGE(kSaName[l], gn_sa_group_mlp_pool_split(lv_xyz, o->sa_xyz[l], w.ball_idx[l], b, lv_n, c.npoint, c.nsample,
-                                                        c.radius, c.mlp, wps, bps, o->sa_features[l], st));
+        GN_STAGE(kSaName[l], gn_sa_group_mlp_pool_split(lv_xyz_of[l], o->sa_xyz[l], w.ball_idx[l], b, lv_pts[l], c.npoint,
+                                                        c.nsample, c.radius, c.mlp, wps, bps, o->sa_features[l], s));
       else
-        GN_STAGE(kSaName[l], gn_sa_group_mlp_pool(lv_xyz, nullptr, o->sa_xyz[l], w.ball_idx[l], b, lv_n, c.npoint,
-                                                  c.nsample, 0, c.radius, c.mlp, wp, bp, o->sa_features[l], st));
+        GN_STAGE(kSaName[l], gn_sa_group_mlp_pool(lv_xyz_of[l], nullptr, o->sa_xyz[l], w.ball_idx[l], b, lv_pts[l], c.npoint,
+                                                  c.nsample, 0, c.radius, c.mlp, wp, bp, o->sa_features[l], s));
     } else {
       if (wt->use_split)
-        GN_STAGE(kLin[l], gn_point_linear_split(lv_feat, b * lv_n, c.cin, c.mlp[0], wt->sa_pre_split[l].w[0],
-                                                wt->sa_pre_split[l].b[0], w.pfeat[l], st));
+        GN_STAGE(kLin[l], gn_point_linear_split(lv_feat_of[l], b * lv_pts[l], c.cin, c.mlp[0], wt->sa_pre_split[l].w[0],
+                                                wt->sa_pre_split[l].b[0], w.pfeat[l], s));
       else
-        GN_STAGE(kLin[l], gn_point_linear(lv_feat, b * lv_n, c.cin, c.mlp[0], wt->sa_pre[l].w[0], wt->sa_pre[l].b[0],
-                                          w.pfeat[l], st));
+        GN_STAGE(kLin[l], gn_point_linear(lv_feat_of[l], b * lv_pts[l], c.cin, c.mlp[0], wt->sa_pre[l].w[0], wt->sa_pre[l].b[0],
+                                          w.pfeat[l], s));
       if (wt->use_split)
-        GN_STAGE(kSaName[l], gn_sa_hoisted_mlp_pool_split(lv_xyz, w.pfeat[l], o->sa_xyz[l], w.ball_idx[l], b, lv_n, c.npoint,
-                                                          c.nsample, c.radius, c.mlp, wps, bps, o->sa_features[l], st));
+        GN_STAGE(kSaName[l], gn_sa_hoisted_mlp_pool_split(lv_xyz_of[l], w.pfeat[l], o->sa_xyz[l], w.ball_idx[l], b, lv_pts[l],
+                                                          c.npoint, c.nsample, c.radius, c.mlp, wps, bps, o->sa_features[l], s));
       else
-        GN_STAGE(kSaName[l], gn_sa_hoisted_mlp_pool(lv_xyz, w.pfeat[l], o->sa_xyz[l], w.ball_idx[l], b, lv_n, c.npoint,
-                                                    c.nsample, c.radius, c.mlp, wp, bp, o->sa_features[l], st));
+        GN_STAGE(kSaName[l], gn_sa_hoisted_mlp_pool(lv_xyz_of[l], w.pfeat[l], o->sa_xyz[l], w.ball_idx[l], b, lv_pts[l], c.npoint,
+                                                    c.nsample, c.radius, c.mlp, wp, bp, o->sa_features[l], s));
     }
-    lv_xyz = o->sa_xyz[l];
-    lv_feat = o->sa_features[l];
-    lv_n = c.npoint;
+    return GN_OK;
+  };
+  auto three_nn = [&](int i, gn_stream_t s) -> int {       // i = 0: fp1 (sa3 <- sa4), 1: fp2 (sa2 <- sa3)
+    if (i == 0)
+      GN_STAGE("three_nn[fp1]", gn_three_nn(o->sa_xyz[2], o->sa_xyz[3], b, kSa[2].npoint, kSa[3].npoint, w.d2[0], w.i3[0], s));
+    else
+      GN_STAGE("three_nn[fp2]", gn_three_nn(o->sa_xyz[1], o->sa_xyz[2], b, kSa[1].npoint, kSa[2].npoint, w.d2[1], w.i3[1], s));
+    return GN_OK;
+  };
+#define GN_TRY(call)                 \
+  do {                               \
+    const int rc__ = (call);         \
+    if (rc__ != GN_OK) return rc__;  \
+  } while (0)
+#define GN_HIP(call, what)                                                                      \
+  do {                                                                                          \
+    const hipError_t e__ = (call);                                                              \
+    if (e__ != hipSuccess) {                                                                    \
+      set_error("graspnet_forward: %s failed: %s", what, hipGetErrorString(e__));               \
+      return GN_ERR_LAUNCH;                                                                     \
+    }                                                                                           \
+  } while (0)
+
+  ForkCtx *fk = (!hook && fork_enabled()) ? fork_ctx(as_stream(st)) : nullptr;
+  if (fk) {
+    hipStream_t main_s = as_stream(st), side_s = fk->side;
+    gn_stream_t side = reinterpret_cast<gn_stream_t>(side_s);
+    // side: grid build (needs the cloud only) beside the SA1 sampler
+    GN_HIP(hipEventRecord(fk->ev[0], main_s), "event record");
+    GN_HIP(hipStreamWaitEvent(side_s, fk->ev[0], 0), "stream wait");
+    if (w.grid) {
+      GN_TRY(gn_grid_build(cloud, b, n, kSa[0].radius, w.grid, side));
+      GN_HIP(hipEventRecord(fk->ev[1], side_s), "event record");
+    }
+    GN_TRY(sample(0, st));
+    GN_HIP(hipEventRecord(fk->ev[2], main_s), "event record");
+    // side: the deeper levels' geometry behind SA1's centres -- samplers, ball queries, three_nn
+    GN_HIP(hipStreamWaitEvent(side_s, fk->ev[2], 0), "stream wait");
+    for (int l = 1; l < 4; ++l) {
+      GN_TRY(sample(l, side));
+      GN_TRY(query(l, side));
+      GN_HIP(hipEventRecord(fk->ev[2 + l], side_s), "event record");
+    }
+    GN_TRY(three_nn(0, side));
+    GN_TRY(three_nn(1, side));
+    GN_HIP(hipEventRecord(fk->ev[6], side_s), "event record");
+    // main: SA1's query + MLP meanwhile, then each level as its geometry arrives
+    if (w.grid) GN_HIP(hipStreamWaitEvent(main_s, fk->ev[1], 0), "stream wait");
+    GN_TRY(query(0, st));
+    GN_TRY(features(0, st));
+    for (int l = 1; l < 4; ++l) {
+      GN_HIP(hipStreamWaitEvent(main_s, fk->ev[2 + l], 0), "stream wait");
+      GN_TRY(features(l, st));
+    }
+    GN_HIP(hipStreamWaitEvent(main_s, fk->ev[6], 0), "stream wait");       // the join: nothing is left on the side stream
+  } else {
+    // one grid over the input cloud serves SA1's ball query and CloudCrop's cylinder query
+    if (w.grid) GN_STAGE("grid_build", gn_grid_build(cloud, b, n, kSa[0].radius, w.grid, st));
+    // ---- 4 set-abstraction levels (backbone.py:105-121)
+    for (int l = 0; l < 4; ++l) {
+      GN_TRY(sample(l, st));
+      GN_TRY(query(l, st));
+      GN_TRY(features(l, st));
+    }
+    GN_TRY(three_nn(0, st));
+    GN_TRY(three_nn(1, st));
   }
 
   // ---- 2 feature-propagation levels (backbone.py:124-125)
@@ -179,7 +301,6 @@ extern "C" int gn_graspnet_forward(const gn_weights *wt, const float *cloud, int
   {
     const float *const wp[2] = {wt->fp[0].w[0], wt->fp[0].w[1]};
     const float *const bp[2] = {wt->fp[0].b[0], wt->fp[0].b[1]};
-    GN_STAGE("three_nn[fp1]", gn_three_nn(o->sa_xyz[2], o->sa_xyz[3], b, kSa[2].npoint, kSa[3].npoint, w.d2[0], w.i3[0], st));
     const void *const wps[2] = {wt->fp_split[0].w[0], wt->fp_split[0].w[1]};
     const float *const bps[2] = {wt->fp_split[0].b[0], wt->fp_split[0].b[1]};
     if (wt->use_split)
@@ -192,7 +313,6 @@ extern "C" int gn_graspnet_forward(const gn_weights *wt, const float *cloud, int
   {
     const float *const wp[2] = {wt->fp[1].w[0], wt->fp[1].w[1]};
     const float *const bp[2] = {wt->fp[1].b[0], wt->fp[1].b[1]};
-    GN_STAGE("three_nn[fp2]", gn_three_nn(o->sa_xyz[1], o->sa_xyz[2], b, kSa[1].npoint, kSa[2].npoint, w.d2[1], w.i3[1], st));
     const void *const wps[2] = {wt->fp_split[1].w[0], wt->fp_split[1].w[1]};
     const float *const bps[2] = {wt->fp_split[1].b[0], wt->fp_split[1].b[1]};
     if (wt->use_split)

@@ -26,30 +26,9 @@
 #include <stdlib.h>
 
 #include "gn_common.h"
+#include "fps_util.h"
 
 namespace gn {
-
-__device__ __forceinline__ int bitrev_bits(int v, int bits) {
-  return bits ? (int)(__brev((unsigned)v) >> (32 - bits)) : 0;
-}
-
-// v_min_f32 without the canonicalising v_max pair hipcc wraps around fminf(): IEEE min, returns
-// the non-NaN operand like CUDA's min(float,float) (sampling_gpu.cu:111).
-__device__ __forceinline__ float vmin(float a, float b) {
-  float r;
-  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
-// position in rank order -> original point index, or -1 for padding.
-// qmagic = ceil(2^32 / Q): floor(p / Q) == umulhi(p, qmagic) for p < 2^15 <= 2^32 / Q (host checks).
-__device__ __forceinline__ int pos_to_k(int p, int bs, int lg, int Q, unsigned qmagic, int n) {
-  const int r = Q == 1 ? p : (int)__umulhi((unsigned)p, qmagic);
-  const int q = p - r * Q;
-  if (r >= bs) return -1;
-  const int k = q * bs + bitrev_bits(r, lg);
-  return k < n ? k : -1;
-}
 
 template <int NT, int PPT>
 __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ xyz, int n, int m,
@@ -932,26 +911,32 @@ __global__ __launch_bounds__(1024) void fps_global_kernel(const float *__restric
   }
 }
 
-// pointnet2/_ext_src/include/cuda_utils.h:18-24 opt_n_threads()
-static int ref_block_size(int n) {
-  int p = 0;
-  while ((2 << p) <= n) ++p;  // floor(log2 n)
-  int t = 1 << p;
-  return t > 512 ? 512 : (t < 1 ? 1 : t);
-}
-
 static const int kRegCapacity = 24576;  // largest NT*PPT instantiated below
+
+// GN_FPS_CELL=<16|32>: take the cell kernel (fps_cell.hip) with that many regions per axis for clouds the register
+// kernels would serve too (A/B measurements, tests); GN_FPS_CELL=0: never take it (the tier / any-n kernels run)
+static int fps_cell_env() {
+  const char *e = getenv("GN_FPS_CELL");       // read per call: tests flip it inside one process
+  return e ? atoi(e) : -1;
+}
+static int fps_cell_forced(int n) {
+  const int v = fps_cell_env();
+  return (v == 16 || v == 32) && n >= 1024 && fps_cell_supports(n, v) ? v : 0;
+}
 
 }  // namespace gn
 
 extern "C" size_t gn_fps_workspace_bytes(int b, int n) {
   if (b <= 0 || n <= 0) return 0;
-  const int bs = gn::ref_block_size(n);
+  const int bs = gn::fps_ref_block_size(n);
   const int Q = (n + bs - 1) / bs;
   const long need = (long)bs * Q;
-  if (need <= gn::kRegCapacity) return 0;
-  if (need <= 1024L * 64) return (size_t)b * 3 * 1024 * 64 * sizeof(float);   // rank-ordered SoA copy (tier kernel)
-  return (size_t)b * (size_t)n * sizeof(float);
+  if (need <= 4096 && !gn::fps_cell_forced(n)) return 0;
+  if (need <= gn::kRegCapacity) return (size_t)b * gn::fps_cell_workspace_bytes_one(n, gn::fps_cell_forced(n));   // tie-tracking calls
+  size_t one = (size_t)n * sizeof(float);                                       // any-n kernel: the reference's `temp`
+  if (need <= 1024L * 64) one = 3 * 1024 * 64 * sizeof(float);                  // rank-ordered SoA copy (tier kernel)
+  if (gn::fps_cell_supports(n)) one = one > gn::fps_cell_workspace_bytes_one(n) ? one : gn::fps_cell_workspace_bytes_one(n);
+  return (size_t)b * one;
 }
 
 extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m, void *workspace,
@@ -962,7 +947,7 @@ extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m,
   if (b == 0 || m == 0) return GN_OK;
   GN_REQUIRE(xyz && idx, "furthest_point_sampling: null pointer");
   GN_REQUIRE((long)n * 3 < 0x7fffffffL, "furthest_point_sampling: n too large");
-  const int bs = ref_block_size(n);
+  const int bs = fps_ref_block_size(n);
   int lg = 0;
   while ((1 << lg) < bs) ++lg;
   const int Q = (n + bs - 1) / bs;
@@ -972,6 +957,20 @@ extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m,
   hipStream_t s = as_stream(stream);
   bool tie_written = false;
   static const int variant = []() { const char *e = getenv("GN_FPS_VARIANT"); return e ? atoi(e) : 4; }();
+  // the cell kernel (fps_cell.hip) serves every cloud beyond the register kernels' 24 576 positions, and -- when the
+  // caller wants the tie report (the fused path: it lets SA2-4 return the identity prefix, 0.86 ms of chains) -- also the
+  // sizes the plain register kernels serve without tracking ties (measured at n = 10 000: 2.54 vs 2.42 ms); the model's own
+  // 20 000-point level keeps fps_region_kernel (1.69 ms; the cell kernel takes 2.7 there)
+  const int cell_s = fps_cell_forced(n);
+  const bool region_band = need > 1024 * 16 && need <= 1024 * 20 && (variant == 4 || variant == 3);
+  const bool cell_for_ties = tie_out != nullptr && workspace != nullptr && need > 4096 && need <= kRegCapacity && !region_band;
+  if (cell_s || (fps_cell_env() != 0 && fps_cell_supports(n) && (need > kRegCapacity || cell_for_ties))) {
+    GN_REQUIRE(workspace != nullptr, "furthest_point_sampling: workspace required for n=%d", n);
+    const int rc = fps_cell_launch(xyz, b, n, m, bs, lg, Q, qmagic, workspace, idx, new_xyz, tie_out, cell_s, s);
+    if (rc != GN_OK) return rc;
+    GN_CHECK_LAUNCH("furthest_point_sampling");
+    return GN_OK;
+  }
 #define GN_FPS_LAUNCH(NT, PPT)                                                                    \
   hipLaunchKernelGGL((fps_reg_kernel<NT, PPT>), dim3(b), dim3(NT), (NT) * (PPT) <= 4096 ? (size_t)n * 3 * sizeof(float) : 0, \
                      s, xyz, n, m, bs, lg, Q, qmagic, idx, new_xyz, prefix_ok)

@@ -56,8 +56,11 @@ const char *gn_version(void);
  * Semantics kept: idx[0]=0; points with x^2+y^2+z^2 <= 1e-3 are never
  * selected; ties resolved in the reference's block-tree order for block size
  * opt_n_threads(N).  `workspace` must hold gn_fps_workspace_bytes(B,N) bytes
- * (the reference's `temp` scratch, sampling.cpp:78-80); it may be NULL when
- * that function returns 0.  new_xyz (B,M,3) is optional (NULL to skip): the
+ * (the reference's `temp` scratch, sampling.cpp:78-80; for clouds beyond one
+ * CU's registers the region-sorted copy of csrc/fps_cell.hip); it may be NULL
+ * when that function returns 0, and for N <= 24576 in any case (a call that
+ * asks for tie_out then runs a kernel that does not track ties and reports 0).
+ * new_xyz (B,M,3) is optional (NULL to skip): the
  * sampled coordinates, i.e. gather_points() fused in.
  * Optional, for the fused path (NULL otherwise):
  *   tie_out (B) i32   : the first iteration whose maximum was shared by points at different

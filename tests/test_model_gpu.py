@@ -440,6 +440,31 @@ def test_graph_captured_forward_matches_eager(net, clouds):
     assert torch.equal(c2, c0.flip(0)) and torch.equal(g2, g0.flip(0))
 
 
+def test_forked_forward_equals_single_stream_forward(net, clouds, monkeypatch):
+    """gn_graspnet_forward puts the grid build and the deeper levels' geometry (samplers, ball queries, three_nn) on a side
+    stream of its own, event-ordered against the caller's stream; GN_FORWARD_FORK=0 keeps everything on the caller's
+    stream: every output identical, also when calls on two caller streams are interleaved, and nothing left running on
+    a side stream when the caller's stream has drained"""
+    x = clouds.cuda()
+    monkeypatch.setenv("GN_FORWARD_FORK", "0")
+    ep0 = net({"point_clouds": x})
+    g0, c0 = net.decode_padded(ep0)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("GN_FORWARD_FORK", "1")
+    outs = []
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for i in range(6):
+        with torch.cuda.stream(streams[i % 2]):
+            ep = net({"point_clouds": x})
+            outs.append((ep, net.decode_padded(ep)))
+    for s in streams:
+        s.synchronize()                     # the callers' streams only: the join must have brought the side work in
+    for ep, (g, c) in outs:
+        assert torch.equal(c, c0) and torch.equal(g, g0)
+        for k in ("sa1_inds", "sa2_inds", "sa3_xyz", "sa4_xyz", "sa4_features", "fp2_features", "view_score", "grasp_score_pred"):
+            assert torch.equal(ep[k], ep0[k]), k
+
+
 def test_pipelined_batches_equal_one_at_a_time(net):
     """PipelinedGraspNet: batches in flight on several streams give exactly the rows of one-at-a-time calls (each call takes its
     workspace from its own stream's allocator pool; nothing is shared but the weights)"""

@@ -119,6 +119,65 @@ def test_fps_tie_step_is_exact(variant, seed):
         assert min(want) == 0x7fffffff
 
 
+@pytest.mark.parametrize("n,m,variant,cell", [(20000, 2048, "uniform", "32"), (20000, 700, "surface", "16"), (5000, 500, "surface", "16"),
+                                              (16384, 300, "uniform", "16"), (4100, 2048, "uniform", "32"), (33000, 300, "surface", None),
+                                              (50000, 2048, "uniform", None), (70000, 300, "uniform", None),
+                                              (140000, 200, "uniform", None), (262144, 64, "uniform", None)])
+def test_fps_cell_kernel_bit_exact(E, oracle, monkeypatch, n, m, variant, cell):
+    """fps_cell.hip (regions of 64-slot rows in an L2-resident workspace, exact work skipping): the default above 24 576
+    positions, forced through GN_FPS_CELL for the sizes the register kernels serve; 16 x 16 and 32 x 32 regions, 1 / 2 / 4
+    rows per region, duplicated points (surface), a few never-sampled points near the origin"""
+    if cell is not None:
+        monkeypatch.setenv("GN_FPS_CELL", cell)
+    x = _cloud(900 + n, 2, n, variant)
+    x[0, 5:40] *= 0.01                  # ||p||^2 <= 1e-3: skipped by the reference (sampling_gpu.cu:105)
+    x[1, 0] = 0.001                     # the first sample itself is a skipped point
+    want = oracle.furthest_point_sampling(x, m)
+    got = E.furthest_point_sampling(_dev(x), m).cpu()
+    assert torch.equal(got, want)
+
+
+def test_fps_cell_kernel_ties_and_skips(E, oracle, monkeypatch):
+    """the adversarial cases of the register kernels on the cell kernel: every point at one of two tied locations (the
+    reference's tree order decides), every point skipped (index 0 throughout), exact duplicates of the whole cloud"""
+    monkeypatch.setenv("GN_FPS_CELL", "16")
+    n = 4096
+    x = torch.zeros(2, n, 3)
+    x[:, :, 0] = 1.0
+    x[:, 0] = torch.tensor([0.0, 0.0, 1.0])
+    x[1, 5::7, 1] = 0.25
+    want = oracle.furthest_point_sampling(x, 40)
+    assert torch.equal(E.furthest_point_sampling(_dev(x), 40).cpu(), want)
+    y = torch.full((1, 5000, 3), 0.01)
+    got = E.furthest_point_sampling(_dev(y), 16).cpu()
+    assert torch.equal(got, oracle.furthest_point_sampling(y, 16)) and not got.any()
+    z = _cloud(31, 1, 3000, "uniform").repeat(1, 3, 1)       # every location three times
+    assert torch.equal(E.furthest_point_sampling(_dev(z), 900).cpu(), oracle.furthest_point_sampling(z, 900))
+
+
+@pytest.mark.parametrize("n,variant,seed,cell", [(20000, "uniform", 1024, "32"), (20000, "surface", 1000, "16"),
+                                                 (50000, "uniform", 1000, None), (30000, "surface", 1003, None)])
+def test_fps_cell_tie_step_is_exact(monkeypatch, n, variant, seed, cell):
+    """the cell kernel's tie report against the numpy walk (as test_fps_tie_step_is_exact for the region kernel), at
+    config[3]'s 50 000 points too: behind it SA2-4 take the identity-prefix shortcut there as well"""
+    from graspnet_amd import _lib as L
+    lib = L.lib()
+    if cell is not None:
+        monkeypatch.setenv("GN_FPS_CELL", cell)
+    b = 4 if n <= 20000 else 2
+    x = _cloud(seed, b, n, variant)
+    xd = x.cuda()
+    ws = torch.empty(max(int(lib.gn_fps_workspace_bytes(b, n)), 16), dtype=torch.uint8, device="cuda")
+    idx = torch.empty(b, 2048, dtype=torch.int32, device="cuda")
+    want = [_first_tie_between_distinct_points(x[i].numpy(), 2048) for i in range(b)]
+    for _ in range(2):
+        tie = torch.full((b,), -7, dtype=torch.int32, device="cuda")
+        L.check(lib.gn_furthest_point_sampling(xd.data_ptr(), b, n, 2048, ws.data_ptr(), idx.data_ptr(), None,
+                                               tie.data_ptr(), None, torch.cuda.current_stream().cuda_stream), "fps")
+        torch.cuda.synchronize()
+        assert tie.cpu().tolist() == want
+
+
 def test_fps_warm_start_behind_a_tie(oracle):
     """the deeper samplers behind SA1's tie report: steps below the reported step are written as the identity prefix, the
     running distances rebuilt without the arg-max chain, the chain run from there.  Uniform scenes 1024.. hold ties at

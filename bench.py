@@ -104,7 +104,7 @@ def cpu_baseline(n_points, reps1, reps8):
 
 def pmc_file():
     """The committed PMC passes of the bench command (HBM bytes per launch); newest round first."""
-    for name in ("r2_pmc_traffic.json", "r1g_pmc_traffic.json"):
+    for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1g_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
@@ -114,14 +114,46 @@ def pmc_file():
     return None, {}
 
 
-def op_rooflines(dev, reps=20):
+def op_rooflines(dev, reps=20, n_points=20000):
     """The drop-in operators BASELINE.json's metric names, at SA sizes (B=8): algorithmic bytes / HIP-event
-    time, against the 8 TB/s HBM peak; PMC bytes per launch beside them where a committed pass has them."""
+    time, against the 8 TB/s HBM peak; PMC bytes per launch beside them where a committed pass has them.
+    n_points=50000: config[3]'s stress shapes (M=2048 centres, nsample 64; the N-proportional byte terms scale x2.5)."""
     from graspnet_amd import pointnet2_ext as E, synthetic as S
     out = {}
-    xyz = S.make_batch(1000, 8, 20000).to(dev)
+    xyz = S.make_batch(1000, 8, n_points).to(dev)
     ctr = xyz[:, :2048].contiguous()
     _, pmc = pmc_file()
+    if n_points != 20000:
+        sfx = "_n%d" % n_points
+
+        def timed3(fn):
+            fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / reps * 1e-3
+
+        def rec3(name, nbytes, t, bound, **extra):
+            r = {"bytes": nbytes, "ms": t * 1e3, "GBps": nbytes / t / 1e9, "frac_hbm": nbytes / t / PEAK_HBM, "bound": bound,
+                 "pmc_bytes": pmc.get(name, {}).get("traffic_bytes")}
+            r.update(extra)
+            out[name] = r
+        nb = n_points * 12
+        t = timed3(lambda: E.ball_query(ctr, xyz, 0.04, 64))
+        rec3("ball_query_sa1" + sfx, (nb + 24576 + 524288) * 8, t,
+             "latency / VALU issue (grid cells then a sorted 64-lane register), HBM-trivial",
+             tests_per_s_brute_force_equivalent=8 * 2048 * n_points / t)
+        xt = xyz.transpose(1, 2).contiguous()
+        idx1 = E.ball_query(ctr, xyz, 0.04, 64)
+        t = timed3(lambda: E.group_points(xt, idx1))
+        rec3("group_points_sa1" + sfx, (nb + 524288 + 1572864) * 8, t, "hbm (write)")
+        t = timed3(lambda: E.furthest_point_sampling(xyz, 2048))
+        rec3("furthest_point_sampling" + sfx, (nb + 8192) * 8, t, "latency (serial chain of 2047 steps per cloud on one CU each)",
+             us_per_iteration=t * 1e6 / 2047)
+        return out
 
     def timed(fn):
         fn()
@@ -155,6 +187,71 @@ def op_rooflines(dev, reps=20):
     t = timed(lambda: E.cylinder_query(seeds, xyz, rot, 0.05, -0.02, 0.04, 64))
     rec("cylinder_query", 551296 * 8, t, "latency / VALU issue, HBM-trivial")
     return out
+
+
+def postprocess_leg(net, clouds, dev, reps=10):
+    """config[4]'s steps around the network on the batch's decoded scenes, all on the device: per scene the voxel
+    down-sample of its cloud (open3d's, restated) + ModelFreeCollisionDetector.detect (utils/collision_detector.py:69-129, the
+    step README.md:72 calls slow), then sort + NMS of the whole batch.  Beside it the numpy restatement (oracle/post_oracle.py,
+    the reference's own arithmetic) on ONE scene as the stated CPU baseline."""
+    from graspnet_amd import postprocess as P
+    ep = net({"point_clouds": clouds})
+    g, c = net.decode_padded(ep)
+    torch.cuda.synchronize()
+    B = clouds.shape[0]
+
+    def ev_time(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            r = fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n, r
+
+    t_vox, dets = ev_time(lambda: [P.ModelFreeCollisionDetector(clouds[i], voxel_size=0.01) for i in range(B)], reps)
+    nvox = [int(d.scene_points.shape[0]) for d in dets]
+    t_col, cms = ev_time(lambda: torch.cat([dets[i].detect_padded(g[i:i + 1], c[i:i + 1], approach_dist=0.05, collision_thresh=0.01)
+                                            for i in range(B)]), reps)
+    t_nms, (out, oc) = ev_time(lambda: P.sort_and_nms(g, c, drop_mask=cms, nms=True), reps)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        d2 = [P.ModelFreeCollisionDetector(clouds[i], voxel_size=0.01) for i in range(B)]
+        cm2 = torch.cat([d2[i].detect_padded(g[i:i + 1], c[i:i + 1], approach_dist=0.05, collision_thresh=0.01) for i in range(B)])
+        P.sort_and_nms(g, c, drop_mask=cm2, nms=True)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps * 1e3
+    res = {"workload": "batch of %d decoded scenes (%d-pt clouds, ~%d grasps each): voxel down-sample 0.01 m + collision detect "
+                       "(approach_dist 0.05, thresh 0.01) per scene, sort + NMS (0.03 m, 30 deg) batched" %
+                       (B, clouds.shape[1], int(c.float().mean().item())),
+           "ms_per_batch": wall, "voxel_down_sample_ms": t_vox, "collision_detect_ms": t_col, "grasp_nms_ms": t_nms,
+           "scene_voxels": nvox[:4], "kept_after_collision_and_nms": oc.cpu().tolist()[:4],
+           "bound": "voxel: float64 atomics on a hash grid (latency / atomic bound, one host sync per scene for the count); "
+                    "collision: float64 VALU (17-row transform + 5 box tests per scene point and grasp: %.2f G point-grasp tests "
+                    "per batch); nms: LDS bitonic sort + a serial greedy sweep per scene"
+                    % (sum(nvox[i] * int(c[i]) for i in range(B)) / 1e9)}
+    try:
+        import numpy as np
+        from oracle import post_oracle as PO
+        pts = clouds[0].cpu().numpy()
+        garr = g[0, :int(c[0])].cpu().numpy()
+        t0 = time.perf_counter()
+        sp = PO.voxel_down_sample(pts, 0.01)
+        t1 = time.perf_counter()
+        wcm, _, _ = PO.collision_detect(sp, garr, approach_dist=0.05, collision_thresh=0.01, voxel_size=0.01)
+        t2 = time.perf_counter()
+        keep = PO.nms_grasp(garr[~wcm], 0.03, 30.0 / 180.0 * np.pi)
+        t3 = time.perf_counter()
+        res["cpu_numpy_one_scene_ms"] = {"voxel_down_sample": (t1 - t0) * 1e3, "collision_detect": (t2 - t1) * 1e3,
+                                         "nms": (t3 - t2) * 1e3, "total": (t3 - t0) * 1e3, "kept": int(len(keep)),
+                                         "note": "oracle/post_oracle.py (numpy, the reference's arithmetic) on scene 0 of the batch; "
+                                                 "x%d for the batch" % B}
+        res["same_collision_mask_as_numpy"] = bool((cms[0, :int(c[0])].cpu().numpy() == wcm).all())
+    except Exception as ex:       # the CPU side is a reported baseline only
+        res["cpu_numpy_one_scene_ms"] = {"error": str(ex)[:200]}
+    return res
 
 
 def free_port():
@@ -197,14 +294,14 @@ def main():
                          "path with several ranks sharing one GPU)")
     ap.add_argument("--legs", default="all",
                     help="all | headline (only the timed headline leg + the isolated per-kernel pass: what the rocprofv3 passes "
-                         "run) | comma list of the legs beside the headline: single,other,f32,graph,ops,cpu")
+                         "run) | comma list of the legs beside the headline: single,other,f32,graph,ops,cpu,cfg3,post")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, form the process group, print {n_gpus, ranks_seen, backend} and stop: checks the "
                          "N-rank launch without touching a GPU (CPU tests, with --backend gloo)")
     ap.add_argument("--cpu-reps", type=int, default=10, help="timed config[0] calls of the CPU baseline (config[1]: a third)")
     args = ap.parse_args()
-    all_legs = {"single", "other", "f32", "graph", "ops", "cpu"}
+    all_legs = {"single", "other", "f32", "graph", "ops", "cpu", "cfg3", "post"}
     legs = all_legs if args.legs == "all" else (set() if args.legs == "headline" else set(args.legs.split(",")))
     if not legs <= all_legs:
         raise SystemExit("--legs: unknown leg in %r" % (args.legs,))
@@ -380,6 +477,34 @@ def main():
             del gnet
         extra["hipgraph_latency_ms"] = lat
         log("hipGraph latency legs done: %s" % lat)
+
+    if world == 1 and "cfg3" in legs:
+        # config[3] of BASELINE.json: dense 50 000-pt clouds (M=2048 seeds, nsample-64 ball query), same network
+        n3 = 50000
+        sets3 = [S.make_batch(3000 + j * B, B, n3, "uniform").to(dev) for j in range(2)]
+        k3s = max(6, min(args.steps, 24))
+        e3m, _, l3 = timed_leg(net, sets3, streams, k3s, len(streams))
+        e3s, _, _ = timed_leg(net, sets3, streams[:1], max(4, k3s // 3), 2)
+        net.timing = {}
+        run_steps(net, sets3, streams[:1], 4, gather=False)
+        torch.cuda.synchronize()
+        st3 = averages(net.timing)
+        net.timing = None
+        extra["config3_n50000"] = {
+            "workload": "config[3]: batch %d x %d-pt synthetic `uniform` clouds, full forward + pred_decode" % (B, n3),
+            "scenes_per_s": B * k3s / e3m, "ms_per_step": e3m / k3s * 1e3, "steps": k3s, "streams": len(streams),
+            "single_stream_ms_per_forward": e3s / max(4, k3s // 3) * 1e3,
+            "fps_sa1_ms": st3.get("furthest_point_sampling[1]"),
+            "fps_sa1_us_per_iteration": (st3.get("furthest_point_sampling[1]") or 0.0) * 1e3 / 2047.0,
+            "kernel_ms": {k: round(v, 4) for k, v in sorted(st3.items(), key=lambda kv: -kv[1])[:8]},
+            "grasps_last_step": int(l3[2].sum().item()),
+            "op_rooflines": op_rooflines(dev, reps=10, n_points=n3) if "ops" in legs else None}
+        del sets3
+        log("config[3] leg done: %.3f ms/step on %d streams, %.3f ms/forward on one" % (e3m / k3s * 1e3, len(streams),
+                                                                                        extra["config3_n50000"]["single_stream_ms_per_forward"]))
+    if world == 1 and "post" in legs:
+        extra["postprocess"] = postprocess_leg(net, sets[0], dev)
+        log("postprocess leg done")
 
     if rank == 0:
         # dominance by CU-time: FPS is the longest kernel but runs on B of the 256 CUs

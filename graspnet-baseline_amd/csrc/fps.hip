@@ -956,7 +956,8 @@ extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m,
   const unsigned qmagic = Q == 1 ? 0xffffffffu : (unsigned)((0x100000000ull + Q - 1) / Q);
   hipStream_t s = as_stream(stream);
   bool tie_written = false;
-  static const int variant = []() { const char *e = getenv("GN_FPS_VARIANT"); return e ? atoi(e) : 4; }();
+  const char *ve = getenv("GN_FPS_VARIANT");       // read per call: tests and probes flip it inside one process
+  const int variant = ve ? atoi(ve) : 4;
   // the cell kernel (fps_cell.hip) serves every cloud beyond the register kernels' 24 576 positions, and -- when the
   // caller wants the tie report (the fused path: it lets SA2-4 return the identity prefix, 0.86 ms of chains) -- also the
   // sizes the plain register kernels serve without tracking ties (measured at n = 10 000: 2.54 vs 2.42 ms); the model's own

@@ -11,14 +11,17 @@
 //   count    one integer atomicAdd per entry (an integer sum has no order)
 //   scan     exclusive prefix per cloud, one workgroup each
 //   fill     slot = atomicAdd(cursor) -- entries land in their destination's segment in ARBITRARY order
-//   order    segments of <= 64 entries: insertion sort by the lane that owns the destination; longer ones are
-//            rebuilt by the whole wave with an ordered ballot scan over the cloud's entries
+//   order    segments of <= 64 entries: insertion sort by the lane that owns the destination; up to 4096 entries: a
+//            bitonic sort of the segment by the whole wave in LDS (ball_query pads short lists by repeating their first
+//            hit, so real SA index tensors hold many destinations with hundreds of entries); longer ones are rebuilt
+//            with an ordered ballot scan over the cloud's entries
 // Entries whose index lies outside [0, n) are dropped (the reference would write out of bounds).
 #include "gn_common.h"
 
 namespace gn {
 
 constexpr int SORT_MAX = 64;
+constexpr int WSORT_MAX = 4096;     // longest segment a wave sorts in its 16 KB of LDS
 
 __global__ __launch_bounds__(256) void inv_count_kernel(const int32_t *__restrict__ idx, int n, int ne,
                                                         int32_t *__restrict__ cnt) {
@@ -89,7 +92,35 @@ __global__ __launch_bounds__(256) void inv_order_kernel(const int32_t *__restric
       l[j + 1] = v;
     }
   }
-  unsigned long long big = __ballot(s > SORT_MAX);
+  // 64 < s <= WSORT_MAX: the wave sorts the segment in LDS (s log^2 s / 64 compare-exchange steps; the ballot rebuild
+  // below costs ne / 64 steps per destination whatever s is: 2 048 at SA1's 2048 x 64 entries)
+  __shared__ int s_sort[4][WSORT_MAX];
+  volatile int *buf = s_sort[threadIdx.x >> 6];
+  unsigned long long mid = __ballot(s > SORT_MAX && s <= WSORT_MAX);
+  while (mid) {
+    const int src = __ffsll((long long)mid) - 1;
+    mid &= mid - 1;
+    const int slo = __shfl(lo, src), ss = __shfl(s, src);
+    int P = 128;
+    while (P < ss) P <<= 1;
+    for (int i = lane; i < P; i += 64) buf[i] = i < ss ? l[slo + i] : 0x7fffffff;
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 2; k <= P; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = lane; i < P; i += 64) {
+          const int q = i ^ j;
+          if (q > i) {
+            const int x = buf[i], y = buf[q];
+            const bool up = (i & k) == 0;
+            if ((x > y) == up) { buf[i] = y; buf[q] = x; }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    for (int i = lane; i < ss; i += 64) l[slo + i] = buf[i];
+    __builtin_amdgcn_wave_barrier();
+  }
+  unsigned long long big = __ballot(s > WSORT_MAX);
   const int32_t *ib = idx + (size_t)b * ne;
   while (big) {
     const int src = __ffsll((long long)big) - 1;

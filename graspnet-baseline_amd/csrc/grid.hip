@@ -49,7 +49,8 @@ __device__ __forceinline__ int centre_cell(float v, float mn, float inv) {
 __global__ __launch_bounds__(1024) void grid_build_kernel(const float *__restrict__ xyz, int n, float reach,
                                                           GridHeader *__restrict__ hdr, int *__restrict__ cell_start,
                                                           float *__restrict__ sxyz, int32_t *__restrict__ sidx) {
-  constexpr int UB = 5;
+  constexpr int UB = 10;        // points per thread and trip of the histogram / scatter passes (2 trips at n = 20 000)
+  constexpr int UBB = 20;       // ... of the bounds pass, which keeps nothing but six running extremes
   __shared__ int s_cnt[GRID_MAX_CELLS];
   __shared__ float s_red[16 * 6];
   __shared__ int s_scan[16];
@@ -62,9 +63,10 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const float *__restric
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // reads past the cloud return 0 (buffer bounds check): no branch around the loads
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xyz), 0, n * 12, 0x00020000);
-  auto fetch = [&](int k0, float (&x)[UB], float (&y)[UB], float (&z)[UB]) {
+  auto fetch = [&](int k0, auto &x, auto &y, auto &z) {
+    constexpr int NU = sizeof(x) / sizeof(float);
 #pragma unroll
-    for (int u = 0; u < UB; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const int off = (k0 + u * 1024) * 12;
       x[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, off, 0, 0));
       y[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, off, 4, 0));
@@ -75,11 +77,11 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const float *__restric
   // the box of the FINITE coordinates: an Inf / NaN coordinate can never be a hit (every predicate on it is false, as in
   // the reference's scan), so it must not stretch the grid either; cell_coord clamps such a point into an edge cell
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int k0 = t; k0 < n; k0 += UB * 1024) {
-    float x[UB], y[UB], z[UB];
+  for (int k0 = t; k0 < n; k0 += UBB * 1024) {
+    float x[UBB], y[UBB], z[UBB];
     fetch(k0, x, y, z);
 #pragma unroll
-    for (int u = 0; u < UB; ++u)
+    for (int u = 0; u < UBB; ++u)
       if (k0 + u * 1024 < n) {
         const float v[3] = {x[u], y[u], z[u]};
 #pragma unroll
@@ -156,10 +158,13 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const float *__restric
     for (int e = 0; e < PER; ++e) {
       const int v = s_cnt[t * PER + e];
       s_cnt[t * PER + e] = run;
-      cell_start[t * PER + e] = run;
       run += v;
     }
     if (t == 1023) cell_start[GRID_MAX_CELLS] = run;
+    __syncthreads();
+    // the table goes out lane-consecutive (each thread's own 16 entries are 64 bytes apart from its neighbour's: written in
+    // place they were 16 store instructions of 64 cache lines each)
+    for (int i = t; i < GRID_MAX_CELLS; i += 1024) cell_start[i] = s_cnt[i];
     __syncthreads();
   }
   for (int k0 = t; k0 < n; k0 += UB * 1024) {

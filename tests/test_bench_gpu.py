@@ -41,6 +41,13 @@ def test_bench_single_gpu_contract():
     assert set(d["hipgraph_latency_ms"]) == {"B=1", "B=8"} and d["hipgraph_latency_ms"]["B=1"] <= d["hipgraph_latency_ms"]["B=8"] * 1.05
     assert {"ball_query_sa1", "group_points_sa2", "group_points_sa1", "cylinder_query"} <= set(d["op_rooflines"])
     assert "workload" in d["config"] and "model" not in d["config"]
+    # config[3] (dense 50 000-pt clouds) and config[4]'s steps around the network have driver-visible legs of their own
+    c3 = d["config3_n50000"]
+    assert c3["scenes_per_s"] > 250.0 and 0 < c3["fps_sa1_us_per_iteration"] < 4.0 and c3["single_stream_ms_per_forward"] < 8.0
+    assert {"ball_query_sa1_n50000", "group_points_sa1_n50000", "furthest_point_sampling_n50000"} <= set(c3["op_rooflines"])
+    pp = d["postprocess"]
+    assert pp["ms_per_batch"] > 0 and pp["collision_detect_ms"] > 0 and pp["grasp_nms_ms"] > 0 and pp["same_collision_mask_as_numpy"] is True
+    assert pp["cpu_numpy_one_scene_ms"]["total"] > 0
 
 
 def test_bench_two_ranks_share_the_gpu_over_gloo():

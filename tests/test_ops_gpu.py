@@ -425,6 +425,31 @@ def test_grad_ops(E, oracle, monkeypatch):
                                oracle.three_interpolate_grad(go2, i3, w3, f_n), rtol=1e-5, atol=1e-4)
 
 
+def test_group_points_grad_on_a_real_padded_ball_query(E, oracle):
+    """ball_query pads short neighbour lists by repeating their first hit up to nsample times, so a real SA1 index tensor holds
+    many destinations with hundreds of entries (sparse corners of the cloud): the wave sorts such segments in LDS (<= 4096
+    entries; the ordered ballot rebuild beyond) -- bit-identical to the oracle's sequential loop, and no ms-scale cliff"""
+    import time
+    x = _cloud(71, 2, 20000, "surface")
+    x[:, 15000:] *= 3.0                                    # a sparse halo: balls there hold 1-3 points -> 60+ repeats each
+    c = x[:, ::9][:, :2048].contiguous()
+    idx = oracle.ball_query(c, x, 0.04, 64)
+    idx[0, :100] = 123                                     # and one destination with 6400 entries (> 4096: ballot rebuild)
+    counts = torch.bincount(idx[0].reshape(-1).long(), minlength=20000)
+    assert int((counts > 64).sum()) > 50 and int(counts.max()) > 4096
+    go = torch.rand(2, 4, 2048, 64, generator=torch.Generator().manual_seed(9))
+    want = oracle.group_points_grad(go, idx, 20000)
+    god, idd = _dev(go), _dev(idx)
+    got = E.group_points_grad(god, idd, 20000)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got2 = E.group_points_grad(god, idd, 20000)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.equal(got.cpu(), want) and torch.equal(got2, got)
+    assert dt < 0.02, "group_points_grad on a padded ball_query index took %.1f ms" % (dt * 1e3)
+
+
 def test_knn_bit_exact(oracle):
     from graspnet_amd import knn_ext
     rng = np.random.default_rng(0)

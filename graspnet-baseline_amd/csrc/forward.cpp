@@ -21,8 +21,12 @@ namespace {
 // the SA1 sampler, ~0.2 ms of small-level geometry in front of SA2-4 / FP).  With a side stream per calling stream the
 // geometry runs beside SA1's ball query + MLP, event-ordered (hipEventRecord / hipStreamWaitEvent only: no host sync, no
 // allocation after the first call on a stream, and legal under hipGraph capture -- the side stream is pulled into the
-// capture by its first wait and joins back before the call returns).  Per-stage hooks (profiling) time launches on the
-// caller's stream, so a call with a hook stays on one stream; GN_FORWARD_FORK=0 does the same.
+// capture by its first wait and joins back before the call returns).  OPT-IN (gn_outputs.fork_streams, GN_FORWARD_FORK=1):
+// inside a captured graph the edges are static and the gain is a steady 0.03-0.06 ms per batch; between eagerly issued
+// streams it depends on the hardware queues (and command-processor pipes) the two streams happen to land on -- 2.88 ms per
+// batch of 8 in the best mapping, 3.45-3.8 ms in others, against 2.95 ms unforked -- and with several batches in flight on
+// several streams the extra streams only compete for queues (-2 %).  A call with a per-stage hook (profiling brackets on
+// the caller's stream) never forks.
 struct ForkCtx {
   hipStream_t side = nullptr;
   hipEvent_t ev[8] = {};
@@ -42,7 +46,7 @@ ForkCtx *fork_ctx(hipStream_t main) {
   hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
   (void)hipThreadExchangeStreamCaptureMode(&mode);
   ForkCtx *c = new ForkCtx();
-  bool ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+  bool ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;   // (a high-priority stream: 3.8 ms)
   for (int i = 0; ok && i < kForkEvents; ++i) ok = hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) == hipSuccess;
   (void)hipThreadExchangeStreamCaptureMode(&mode);
   if (!ok) {
@@ -54,9 +58,12 @@ ForkCtx *fork_ctx(hipStream_t main) {
   return c;
 }
 
-bool fork_enabled() {
+// the caller's choice (gn_outputs.fork_streams) unless GN_FORWARD_FORK=0 / 1 overrides it
+bool fork_wanted(bool asked) {
   const char *e = getenv("GN_FORWARD_FORK");
-  return !(e && e[0] == '0');
+  if (e && e[0] == '0') return false;
+  if (e && e[0] == '1') return true;
+  return asked;
 }
 
 struct SaCfg { int npoint; float radius; int nsample; int cin; int mlp[3]; };
@@ -251,7 +258,7 @@ extern "C" int gn_graspnet_forward(const gn_weights *wt, const float *cloud, int
     }                                                                                           \
   } while (0)
 
-  ForkCtx *fk = (!hook && fork_enabled()) ? fork_ctx(as_stream(st)) : nullptr;
+  ForkCtx *fk = (!hook && fork_wanted(o->fork_streams != 0)) ? fork_ctx(as_stream(st)) : nullptr;
   if (fk) {
     hipStream_t main_s = as_stream(st), side_s = fk->side;
     gn_stream_t side = reinterpret_cast<gn_stream_t>(side_s);

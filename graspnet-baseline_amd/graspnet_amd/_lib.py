@@ -38,7 +38,7 @@ class Outputs(ctypes.Structure):             # gn_outputs
                 ("fp2_features", _c_void_p), ("approach", _c_void_p), ("top_view_inds", _c_void_p),
                 ("top_view_score", _c_void_p), ("top_view_xyz", _c_void_p), ("top_view_rot", _c_void_p),
                 ("vp_features", _c_void_p), ("head", _c_void_p), ("crop_uidx", _c_void_p), ("crop_ucount", _c_void_p),
-                ("grasps", _c_void_p), ("counts", _c_void_p)]
+                ("grasps", _c_void_p), ("counts", _c_void_p), ("fork_streams", ctypes.c_int32)]
 
 
 STAGE_HOOK = ctypes.CFUNCTYPE(None, ctypes.c_char_p, _c_int, _c_void_p)   # gn_stage_hook

@@ -54,6 +54,10 @@ class GraspNet:
         self._tables = None
         self._sd = None
         self.timing = None        # set to {} to collect (start,end) HIP events per kernel launch
+        # True: gn_graspnet_forward may run the grid build and the deeper levels' geometry on a side stream of its own
+        # (gn_outputs.fork_streams).  A steady gain only inside a captured hipGraph (GraphedGraspNet sets it while it
+        # captures); between eagerly issued streams it depends on the hardware-queue mapping, so the default is off
+        self.fork = False
         # CloudCrop over de-duplicated (seed, point) rows (default) or over the four full index lists
         self.crop_unique = os.environ.get("GN_CROP_PATH", "unique") != "lists"
         # SA2-4: layer 1's per-point part hoisted out of the per-neighbour MLP (bit-identical, fewer MFMAs)
@@ -182,6 +186,7 @@ class GraspNet:
             top_xyz.data_ptr(), top_rot.data_ptr(), vp.data_ptr(), head.data_ptr())
         o.crop_uidx, o.crop_ucount = uidx.data_ptr(), ucount.data_ptr()
         o.grasps = o.counts = None
+        o.fork_streams = 1 if self.fork else 0
         hook = _NO_HOOK
         if self.timing is not None:
             pending = {}
@@ -442,7 +447,7 @@ class GraphedGraspNet:
     the returned end_points / grasps / counts are the graph's static output tensors (overwritten by the
     next call).  Nothing in the C ABI allocates or synchronises, which is what makes the capture legal."""
 
-    def __init__(self, net, batch, points, warmup=2):
+    def __init__(self, net, batch, points, warmup=2, fork_streams=True):
         self.net = net
         dev = net.device
         self.static_in = torch.zeros((batch, points, 3), dtype=torch.float32, device=dev)
@@ -455,9 +460,13 @@ class GraphedGraspNet:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.end_points = net({"point_clouds": self.static_in})
-            self.grasps, self.counts = net.decode_padded(self.end_points)
+        fork, net.fork = net.fork, fork_streams      # static edges inside the graph: the side stream is a steady gain here
+        try:
+            with torch.cuda.graph(self.graph):
+                self.end_points = net({"point_clouds": self.static_in})
+                self.grasps, self.counts = net.decode_padded(self.end_points)
+        finally:
+            net.fork = fork
 
     def __call__(self, point_clouds):
         self.static_in.copy_(point_clouds[..., 0:3], non_blocking=True)

@@ -339,6 +339,13 @@ typedef struct gn_outputs {          /* device buffers owned by the caller; all 
   int32_t *crop_uidx, *crop_ucount;  /* optional (B,1024,256) / (B,1024): the de-duplicated crop lists */
   float *grasps;                     /* optional (B,1024,17): NULL skips pred_decode */
   int32_t *counts;                   /* (B), with grasps */
+  int32_t fork_streams;              /* 0 (default): every launch on `stream`.  Non-zero: the call may put the grid build and
+                                        the deeper levels' geometry (samplers / ball queries 2-4, three_nn) on a side stream of
+                                        its own, event-ordered and joined again before it returns.  Worth 0.03-0.06 ms of a
+                                        2.8 ms batch inside a captured hipGraph (graspnet_amd.GraphedGraspNet sets it); on
+                                        eagerly issued streams the gain depends on which hardware queues the two streams land
+                                        on (measured 2.88 ... 3.8 ms against 2.95 unforked), and with several batches in
+                                        flight the extra streams only compete for queues (-2 %) */
 } gn_outputs;
 
 /* Optional per-launch hook (profiling): called on the host right before (phase 0) and right after

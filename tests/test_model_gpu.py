@@ -441,16 +441,17 @@ def test_graph_captured_forward_matches_eager(net, clouds):
 
 
 def test_forked_forward_equals_single_stream_forward(net, clouds, monkeypatch):
-    """gn_graspnet_forward puts the grid build and the deeper levels' geometry (samplers, ball queries, three_nn) on a side
-    stream of its own, event-ordered against the caller's stream; GN_FORWARD_FORK=0 keeps everything on the caller's
-    stream: every output identical, also when calls on two caller streams are interleaved, and nothing left running on
+    """with gn_outputs.fork_streams set, gn_graspnet_forward puts the grid build and the deeper levels' geometry (samplers, ball
+    queries, three_nn) on a side stream of its own, event-ordered against the caller's stream; GN_FORWARD_FORK=0 keeps
+    everything on the caller's stream whatever the call asks: every output identical, also when calls on two caller streams are interleaved, and nothing left running on
     a side stream when the caller's stream has drained"""
     x = clouds.cuda()
     monkeypatch.setenv("GN_FORWARD_FORK", "0")
     ep0 = net({"point_clouds": x})
     g0, c0 = net.decode_padded(ep0)
     torch.cuda.synchronize()
-    monkeypatch.setenv("GN_FORWARD_FORK", "1")
+    monkeypatch.delenv("GN_FORWARD_FORK")
+    monkeypatch.setattr(net, "fork", True)                  # gn_outputs.fork_streams
     outs = []
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     for i in range(6):

@@ -7,6 +7,7 @@ from collections import defaultdict
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = name.split("(")[0]
     for pre in ("void gn::", "gn::"):
         if name.startswith(pre):

@@ -21,7 +21,7 @@
 //     coordinates come from LDS right behind the barrier instead of from L2 through the scalar cache.
 //
 // Tie order is the reference's shared-memory tree's: rank(k) = bitrev(k % bs) * Q + k / bs, smallest wins (fps.hip
-// header); it is carried in the key word, ((0x3ffff - rank) << 4) | wave, under the value in a 64-bit ds_max_u64.
+// header); it is carried in the key word, ((0x7ffff - rank) << 4) | wave (never 0: ranks stay below 2^18), under the value in a 64-bit ds_max_u64.
 // The kernel also reports the first step whose maximum was shared by DIFFERENT locations (tie_out), which lets the
 // deeper levels' samplers return the identity prefix (gn_furthest_point_sampling's prefix_ok).
 // Distances are evaluated exactly as sampling_gpu.cu:108-109 writes them (-ffp-contract=off).
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(1024) void fps_cell_kernel(const float *__restrict_
     const float mag = (x * x) + (y * y) + (z * z);
     const f4 v = {x, y, z, ((double)mag <= 1e-3) ? -1.0f : 1e10f};        // sampling_gpu.cu:105-106, sampling.cpp:78-80
     pt[p] = v;
-    rk[p] = ((0x3ffffu - (unsigned)rank_of(k)) << 4) | (unsigned)w;
+    rk[p] = ((0x7ffffu - (unsigned)rank_of(k)) << 4) | (unsigned)w;
   }
   __syncthreads();                       // workspace writes of the whole workgroup are visible to its waves from here
   if (wave >= NWC) return;               // the chain's barriers count the remaining waves only
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(1024) void fps_cell_kernel(const float *__restrict_
     const int g = idx[j];
     int k = 0;                                      // every candidate skipped -> the reference returns index 0
     if (g != -1) {
-      k = pos_to_k((int)(0x3ffffu - ((unsigned)g >> 4)), bs, lg, Q, qmagic, n);
+      k = pos_to_k((int)(0x7ffffu - ((unsigned)g >> 4)), bs, lg, Q, qmagic, n);
       k = k < 0 ? 0 : k;
     }
     idx[j] = k;

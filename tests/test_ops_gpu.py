@@ -153,6 +153,12 @@ def test_fps_cell_kernel_ties_and_skips(E, oracle, monkeypatch):
     assert torch.equal(got, oracle.furthest_point_sampling(y, 16)) and not got.any()
     z = _cloud(31, 1, 3000, "uniform").repeat(1, 3, 1)       # every location three times
     assert torch.equal(E.furthest_point_sampling(_dev(z), 900).cpu(), oracle.furthest_point_sampling(z, 900))
+    # more samples than distinct locations: once every location is taken the maximum is 0.0 and the reference's tree order
+    # alone decides (a winner at distance zero is still a winner, not "no candidate")
+    few = _cloud(32, 2, 50, "uniform").repeat(1, 100, 1)      # 5000 points at 50 locations
+    assert torch.equal(E.furthest_point_sampling(_dev(few), 200).cpu(), oracle.furthest_point_sampling(few, 200))
+    monkeypatch.setenv("GN_FPS_CELL", "32")
+    assert torch.equal(E.furthest_point_sampling(_dev(few), 200).cpu(), oracle.furthest_point_sampling(few, 200))
 
 
 @pytest.mark.parametrize("n,variant,seed,cell", [(20000, "uniform", 1024, "32"), (20000, "surface", 1000, "16"),

@@ -833,7 +833,11 @@ __global__ __launch_bounds__(NWV * 64) void sa_hoist_split_kernel(const float *_
 
 using namespace gn;
 
-static int split_tiles_per_block(int ntiles) {
+// wgs_per_cu: workgroups per CU the grid aims at.  SA1 (two workgroups resident per CU, small weights) is best at 4; the
+// hoisted SA2-4 kernels (one workgroup per CU, 288 registers of resident weights = 295 KB loaded by every workgroup) at 1:
+// measured in isolation at batch 8 (profiles/sa_wgs_sweep.sh) SA2 0.138 -> 0.128 ms, SA3 0.0525 -> 0.0394, SA4 0.0282 -> 0.0242
+// going from 4 to 1 (SA1 0.152 -> 0.185 the other way); GN_SA_WGS_PER_CU overrides both
+static int split_tiles_per_block(int ntiles, int wgs_per_cu) {
   static int cus = 0;
   if (!cus) {
     int dev = 0;
@@ -842,7 +846,7 @@ static int split_tiles_per_block(int ntiles) {
     if (cus <= 0) cus = 256;
   }
   static const int div_env = []() { const char *e = getenv("GN_SA_WGS_PER_CU"); return e ? atoi(e) : 0; }();
-  int tpb = ntiles / (cus * (div_env > 0 ? div_env : 4));
+  int tpb = ntiles / (cus * (div_env > 0 ? div_env : wgs_per_cu));
   return tpb < 1 ? 1 : (tpb > 64 ? 64 : tpb);
 }
 
@@ -864,7 +868,7 @@ extern "C" int gn_sa_group_mlp_pool_split(const float *xyz, const float *new_xyz
     const int ntiles = (int)((long)b * np / (tp / ns));
     const size_t lds = 2 * (size_t)(3 * tp * sp_stride(64) + 3 * tp * sp_stride(64)) + sizeof(float) * (2 * tp * lds_stride(8));
     if ((rc = set_lds_attr(k, lds, "sa_group_mlp_pool_split"))) return;
-    const int tpb = split_tiles_per_block(ntiles);
+    const int tpb = split_tiles_per_block(ntiles, 4);
     hipLaunchKernelGGL(k, dim3((ntiles + tpb - 1) / tpb), dim3(MLP_THREADS), lds, as_stream(stream), xyz, n, new_xyz, idx,
                        np, ntiles, tpb, radius, W, out);
   };
@@ -896,7 +900,7 @@ extern "C" int gn_sa_hoisted_mlp_pool_split(const float *xyz, const float *pfeat
   const SplitWeights W{static_cast<const float *>(wpacked[0]), bias[0], wpacked[1], wpacked[2], bias[1], bias[2]};
   const int ntiles = (int)((long)b * np / (TP / ns));
   constexpr size_t lds = 2 * (3 * TP * sp_stride(128) + 3 * TP * sp_stride(128)) + sizeof(float) * (2 * TP * lds_stride(8) + 128 * 4);
-  const int tpb = split_tiles_per_block(ntiles);
+  const int tpb = split_tiles_per_block(ntiles, 1);
   int rc;
   auto launch = [&](auto k, int threads) {
     if ((rc = set_lds_attr(k, lds, "sa_hoisted_mlp_pool_split"))) return;
@@ -930,7 +934,7 @@ extern "C" int gn_crop_unique_mlp_pool_split(const float *xyz, const float *seed
   const int nseeds = b * m;
   static const int spb_env = []() { const char *e = getenv("GN_CROP_SPB"); return e ? atoi(e) : 0; }();
   int spb = nseeds / 512;    // seeds per workgroup (the 250 KB of resident weights are loaded once per workgroup):
-  spb = spb < 1 ? 1 : (spb > 16 ? 16 : spb);   // two workgroups per CU in the grid at B=8 (16: 6380, 4: 6290 scenes/s)
+  spb = spb < 1 ? 1 : (spb > 16 ? 16 : spb);   // two workgroups per CU in the grid at B=8 (16: 6380, 4: 6290 scenes/s; 32 seeds with a 32-slot table: 0.362 ms, no gain)
   if (spb_env > 0) spb = spb_env > kCropMaxSpb ? kCropMaxSpb : spb_env;   // the kernel's s_cnt[] holds kCropMaxSpb seeds
   constexpr int TP = 96;
   constexpr size_t lds = 2 * (3 * TP * sp_stride(128) + 3 * TP * sp_stride(64)) + sizeof(float) * (2 * TP * lds_stride(8) + 2 * TP * 4);

@@ -158,6 +158,7 @@ extern "C" int gn_graspnet_forward(const gn_weights *wt, const float *cloud, int
                  o->top_view_rot && o->vp_features && o->head,
              "graspnet_forward: null output");
   GN_REQUIRE(!o->grasps == !o->counts, "graspnet_forward: grasps and counts go together");
+  GN_REQUIRE(wt->num_view >= 0 && wt->num_view <= 318, "graspnet_forward: num_view must be 1..318 (0 = 300), got %d", wt->num_view);
   {   // every layer pointer of the weight set that will be used
     auto full = [](const gn_mlp_weights &m, int nl) {
       for (int i = 0; i < nl; ++i)
@@ -330,7 +331,8 @@ extern "C" int gn_graspnet_forward(const gn_weights *wt, const float *cloud, int
                                                       kSa[2].npoint, 256, 256, fp_mlp, wp, bp, o->fp2_features, st));
   }
   const float *seed_xyz = o->sa_xyz[1];
-  const int M = kSeeds, nv = 2 + kViews;
+  const int views = wt->num_view ? wt->num_view : kViews;
+  const int M = kSeeds, nv = 2 + views;
 
   // ---- ApproachNet (modules.py:41-77)
   {
@@ -342,7 +344,7 @@ extern "C" int gn_graspnet_forward(const gn_weights *wt, const float *cloud, int
       GN_STAGE("approach_mlp", gn_approach_mlp_split(o->fp2_features, b * M, 256, nv, wps, bps, o->approach, st));
     else
       GN_STAGE("approach_mlp", gn_approach_mlp(o->fp2_features, b * M, 256, nv, wp, bp, o->approach, st));
-    GN_STAGE("approach_post", gn_approach_post(o->approach, nv, b * M, kViews, wt->views, wt->view_rot, o->top_view_inds,
+    GN_STAGE("approach_post", gn_approach_post(o->approach, nv, b * M, views, wt->views, wt->view_rot, o->top_view_inds,
                                                o->top_view_score, o->top_view_xyz, o->top_view_rot, st));
   }
 

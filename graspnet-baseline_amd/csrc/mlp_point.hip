@@ -175,13 +175,13 @@ extern "C" int gn_approach_mlp(const float *x, int rows, int cin, int nout, cons
   GN_REQUIRE(rows >= 0, "approach_mlp: bad sizes");
   if (rows == 0) return GN_OK;
   GN_REQUIRE(x && wpacked && bias && out, "approach_mlp: null pointer");
-  if (!(cin == 256 && nout == 302)) {
-    set_error("approach_mlp: unsupported configuration cin=%d nout=%d (need 256, 2+300)", cin, nout);
+  if (!(cin == 256 && nout >= 3 && nout <= 320)) {
+    set_error("approach_mlp: unsupported configuration cin=%d nout=%d (need 256 and 3 <= 2+num_view <= 320)", cin, nout);
     return GN_ERR_INVALID_ARG;
   }
   PointMlpArgs a{};
   a.w1 = wpacked[0]; a.b1 = bias[0]; a.w2 = wpacked[1]; a.b2 = bias[1]; a.w3 = wpacked[2]; a.b3 = bias[2];
-  a.x = x; a.out = out; a.ldo = 302; a.ncols_out = 302; a.nrows = rows;
+  a.x = x; a.out = out; a.ldo = nout; a.ncols_out = nout; a.nrows = rows;
   return launch_point_mlp<LOAD_PLAIN, 256, 256, 256, 384, 320, 384, 64, 32, 40, 64, false>(a, as_stream(stream),
                                                                                              "approach_mlp");
 }

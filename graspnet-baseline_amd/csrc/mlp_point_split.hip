@@ -434,13 +434,13 @@ extern "C" int gn_approach_mlp_split(const float *x, int rows, int cin, int nout
   GN_REQUIRE(rows >= 0, "approach_mlp_split: bad sizes");
   if (rows == 0) return GN_OK;
   GN_REQUIRE(x && wpacked && bias && out, "approach_mlp_split: null pointer");
-  if (!(cin == 256 && nout == 302)) {
-    set_error("approach_mlp_split: unsupported configuration cin=%d nout=%d (need 256, 2+300)", cin, nout);
+  if (!(cin == 256 && nout >= 3 && nout <= 320)) {
+    set_error("approach_mlp_split: unsupported configuration cin=%d nout=%d (need 256 and 3 <= 2+num_view <= 320)", cin, nout);
     return GN_ERR_INVALID_ARG;
   }
   PointSplitArgs a{};
   for (int i = 0; i < 3; ++i) { a.w[i] = wpacked[i]; a.b[i] = bias[i]; }
-  a.x = x; a.out = out; a.ldo = 302; a.ncols_out = 302; a.nrows = rows;
+  a.x = x; a.out = out; a.ldo = nout; a.ncols_out = nout; a.nrows = rows;
   if (point_wpc(2) >= 2)
     return launch_point_split<PLOAD_PLAIN, 3, 256, 256, 256, 384, 320, 384, 32, false, 2>(a, as_stream(stream), "approach_mlp_split");
   return launch_point_split<PLOAD_PLAIN, 3, 256, 256, 256, 384, 320, 384, 64, false>(a, as_stream(stream), "approach_mlp_split");

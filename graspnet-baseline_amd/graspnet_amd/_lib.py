@@ -30,7 +30,7 @@ class Weights(ctypes.Structure):             # gn_weights
                 ("decode_rot", _c_void_p), ("cylinder_radius", _c_float), ("hmin", _c_float), ("hmax", _c_float * 4),
                 ("use_split", _c_int), ("sa_split", MlpWeights * 4), ("crop_split", MlpWeights),
                 ("sa_pre_split", MlpWeights * 4), ("fp_split", MlpWeights * 2), ("approach_split", MlpWeights),
-                ("heads_split", MlpWeights)]
+                ("heads_split", MlpWeights), ("num_view", _c_int)]
 
 
 class Outputs(ctypes.Structure):             # gn_outputs

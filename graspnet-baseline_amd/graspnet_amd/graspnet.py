@@ -42,8 +42,8 @@ class GraspNet:
             raise NotImplementedError("graspnet_amd.GraspNet is an inference path (is_training=False)")
         if input_feature_dim != 0:
             raise NotImplementedError("input_feature_dim != 0 is not used by the reference model")
-        if num_depth != 4 or len(hmax_list) != 4 or num_angle != 12 or num_view != 300:
-            raise NotImplementedError("only the reference configuration (300 views, 12 angles, 4 depths) is built")
+        if num_depth != 4 or len(hmax_list) != 4 or num_angle != 12 or not 1 <= int(num_view) <= 318:
+            raise NotImplementedError("built for 12 angles, 4 depths (the reference's heads) and 1..318 approach views")
         self.num_view, self.num_angle, self.num_depth = num_view, num_angle, num_depth
         self.cylinder_radius, self.hmin = float(cylinder_radius), float(hmin)
         self.hmax = (ctypes.c_float * 4)(*[float(h) for h in hmax_list])
@@ -91,6 +91,10 @@ class GraspNet:
         if strict and (missing or unexpected):
             raise RuntimeError("Error(s) in loading state_dict for GraspNet: missing %s unexpected %s"
                                % (missing[:5], unexpected[:5]))
+        k3 = "view_estimator.vpmodule.conv3.weight"
+        if k3 in state_dict and int(state_dict[k3].shape[0]) != 2 + self.num_view:
+            raise RuntimeError("Error(s) in loading state_dict for GraspNet: size mismatch for %s: the checkpoint holds %d views, "
+                               "the model was built with num_view=%d" % (k3, int(state_dict[k3].shape[0]) - 2, self.num_view))
         self._sd = {k: v.detach().clone() for k, v in state_dict.items()}
         self._build()
         return self
@@ -156,6 +160,7 @@ class GraspNet:
         fill(w.approach_split, pk["approach_split"])
         fill(w.heads_split, pk["heads_split"])
         w.use_split = 1 if self.math_split else 0
+        w.num_view = int(self.num_view)
         return w
 
     def _forward_native(self, end_points, xyz):
@@ -558,13 +563,15 @@ def pred_decode(end_points):
         model = priv["model"]
     else:
         dev = end_points["fp2_xyz"].device
-        model = _DEFAULT_DECODERS.get(dev)
+        nview = int(end_points["view_score"].shape[-1]) if "view_score" in end_points else 300
+        model = _DEFAULT_DECODERS.get((dev, nview))
         if model is None:
             model = GraspNet()
             model.device = dev
-            v, vr, dr = geometry.build_tables(300, 12)
+            model.num_view = int(end_points["view_score"].shape[-1]) if "view_score" in end_points else 300
+            v, vr, dr = geometry.build_tables(model.num_view, 12)
             model._tables = (v.to(dev), vr.to(dev), dr.to(dev))
-            _DEFAULT_DECODERS[dev] = model
+            _DEFAULT_DECODERS[(dev, nview)] = model
     grasps, counts = model.decode_padded(end_points)
     cnt = counts.cpu().tolist()          # the only host sync; the reference's callers sync here too (test.py:88)
     return [grasps[i, :c] for i, c in enumerate(cnt)]

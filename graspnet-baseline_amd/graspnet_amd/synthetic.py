@@ -93,7 +93,7 @@ def _shared_mlp(sd, rng, prefix, spec):
                  spec[i + 1], spec[i], 2, bias=False)
 
 
-def make_state_dict(seed=0, calibrated=True):
+def make_state_dict(seed=0, calibrated=True, num_view=NUM_VIEW):
     """Seeded, perturbed weights (random BN statistics/affine, non-zero biases):
     default-initialised BN makes every seed pick the same view.
     With calibrated=True and data/bn_calib_s<seed>.npz present (written by
@@ -108,7 +108,7 @@ def make_state_dict(seed=0, calibrated=True):
     for i in (1, 2):
         _shared_mlp(sd, rng, "%s.fp%d.mlp" % (bb, i), FP_MLP)
     vp = "view_estimator.vpmodule"
-    nv = 2 + NUM_VIEW
+    nv = 2 + num_view
     _conv_bn(sd, rng, vp + ".conv1", vp + ".bn1", 256, 256, 1, True)
     _conv_bn(sd, rng, vp + ".conv2", vp + ".bn2", nv, 256, 1, True)
     _conv_bn(sd, rng, vp + ".conv3", None, nv, nv, 1, True)
@@ -123,6 +123,8 @@ def make_state_dict(seed=0, calibrated=True):
         if os.path.exists(path):
             with np.load(path) as z:
                 for k in z.files:
+                    if num_view != NUM_VIEW and tuple(sd[k].shape) != z[k].shape:
+                        continue            # the calibration file is for 300 views: layers sized by num_view keep their seeds
                     assert k in sd and tuple(sd[k].shape) == z[k].shape, k
                     sd[k] = torch.from_numpy(z[k].copy())
     return sd

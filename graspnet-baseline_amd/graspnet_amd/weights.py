@@ -136,12 +136,15 @@ def prepare(sd, device, num_view=300, num_angle=12):
     l1 = fold_bn(sd[vp + ".conv1.weight"], sd[vp + ".conv1.bias"], sd, vp + ".bn1")
     l2 = fold_bn(sd[vp + ".conv2.weight"], sd[vp + ".conv2.bias"], sd, vp + ".bn2")
     l3 = fold_bn(sd[vp + ".conv3.weight"], sd[vp + ".conv3.bias"], sd, None)
-    nvp = coutp_for(nv)
+    # one kernel shape for every num_view <= 318: 256 -> 256 -> 384 -> 384, layer 3's K padded to 320 (zeros beyond 2+V)
+    if not 3 <= nv <= 320:
+        raise NotImplementedError("num_view must be 1..318 (got %d)" % num_view)
+    nvp, k3 = 384, 320
     out["approach"] = PackedMlp([pack_fragments(*l1), pack_fragments(*l2, coutp=nvp),
-                                 pack_fragments(*l3, cinp=pad_to(nv, 32), coutp=nvp)], device)   # K padded to 320: chunks of 80
+                                 pack_fragments(*l3, cinp=k3, coutp=nvp)], device)
     crop_layers = _shared_mlp_layers(sd, "grasp_generator.crop.mlps", 3)
     out["approach_split"] = PackedMlp([pack_split(l1.w64, l1[1]), pack_split(l2.w64, l2[1], coutp=nvp),
-                                       pack_split(l3.w64, l3[1], cinp=pad_to(nv, 32), coutp=nvp)], device)
+                                       pack_split(l3.w64, l3[1], cinp=k3, coutp=nvp)], device)
     out["crop"] = PackedMlp([pack_fragments(w, b, cinp=8 if i == 0 else None) for i, (w, b) in enumerate(crop_layers)], device)
     # layers 2-3 as split-bf16 fragments for the matrix-core path (layer 1, K = 3, stays fp32)
     out["crop_split"] = PackedMlp([pack_fragments(*crop_layers[0], cinp=8), pack_split(crop_layers[1].w64, crop_layers[1][1]),

@@ -269,7 +269,8 @@ int gn_point_linear_split(const float *x, int rows, int cin, int cout, const voi
                           gn_stream_t stream);
 
 /* ApproachNet conv1/bn1/relu, conv2/bn2/relu, conv3 (models/modules.py:55-57):
- * x (rows,256) -> out (rows, 2+num_view) = [objectness | view scores]. */
+ * x (rows,256) -> out (rows, nout = 2+num_view) = [objectness | view scores], 3 <= nout <= 320; the packed layers are
+ * 256 -> 256 -> 384 -> 384 whatever nout is (layer 3's K padded to 320; zeros beyond nout). */
 int gn_approach_mlp(const float *x, int rows, int cin, int nout, const float *const *wpacked,
                     const float *const *bias, float *out, gn_stream_t stream);
 
@@ -322,6 +323,9 @@ typedef struct gn_weights {
   gn_mlp_weights crop_split;
   gn_mlp_weights sa_pre_split[4];  /* [l].w[0]/b[0], l >= 1 */
   gn_mlp_weights fp_split[2], approach_split, heads_split;   /* all layers split */
+  int num_view;              /* approach views V (models/graspnet.py:64 num_view); 0 = the reference's 300.  1 <= V <= 318: the
+                              * ApproachNet layers are always packed as 256 -> 256 -> 384 -> 384 with K of layer 3 padded to
+                              * 320 (zero rows / columns beyond 2+V), views / view_rot / decode_rot hold V rows */
 } gn_weights;
 
 typedef struct gn_outputs {          /* device buffers owned by the caller; all required unless noted */

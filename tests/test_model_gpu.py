@@ -534,6 +534,29 @@ def test_other_batch_and_cloud_sizes(net, model_oracle, state_dict, B, N, varian
     PU.assert_parity("other sizes: B=%d N=%d %s" % (B, N, variant), ep, pr, rep, rp, tru, model_oracle.pred_decode(tru), MATH)
 
 
+@pytest.mark.parametrize("num_view", [60, 200, 318])
+def test_other_num_view(model_oracle, num_view):
+    """models/graspnet.py:64 takes num_view (a CLI flag of every reference script): the view template, the view -> rotation
+    tables and the ApproachNet layers 256 -> 2+V -> 2+V are sized by it (packed onto the 384-wide kernels); everything under
+    the same parity rule as the 300-view model, top views inside [0, V)"""
+    from graspnet_amd import GraspNet, pred_decode, synthetic as S
+    sd = S.make_state_dict(0, num_view=num_view)
+    cl = S.make_batch(640 + num_view, 2, 5000, "uniform")
+    rep = model_oracle.forward({"point_clouds": cl.clone()}, sd, num_view=num_view)
+    rp = model_oracle.pred_decode(rep)
+    tru = model_oracle.forward({"point_clouds": cl.clone()}, sd, num_view=num_view, f64=True,
+                               force_top_view_inds=rep["grasp_top_view_inds"])
+    net_v = GraspNet(num_view=num_view).load_state_dict(sd)
+    ep = net_v({"point_clouds": cl.cuda()})
+    pr = pred_decode(ep)
+    assert ep["view_score"].shape == (2, 1024, num_view) and int(ep["grasp_top_view_inds"].max()) < num_view
+    PU.assert_parity("num_view=%d: B=2 N=5000" % num_view, ep, pr, rep, rp, tru, model_oracle.pred_decode(tru), MATH)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        GraspNet(num_view=num_view).load_state_dict(S.make_state_dict(0))
+    with pytest.raises(NotImplementedError):
+        GraspNet(num_view=400)
+
+
 def test_refuses_cpu_and_training(state_dict):
     from graspnet_amd import GraspNet
     with pytest.raises(NotImplementedError):

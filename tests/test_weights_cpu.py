@@ -86,3 +86,18 @@ def test_split_of_float64_fold_keeps_more_than_fp32():
     assert float(rel) <= 2.0 ** -25 and float(rel) < float(rel32)
     f = W.Folded(w64, torch.zeros(64, dtype=torch.float64))
     assert f[0].dtype == torch.float32 and f.w64.dtype == torch.float64 and torch.equal(f[0], w64.float())
+
+
+def test_approach_layers_pack_onto_one_shape_for_any_num_view():
+    """weights.prepare packs ApproachNet as 256 -> 256 -> 384 -> 384 (layer 3's K padded to 320) whatever num_view <= 318 is:
+    the kernels are instantiated once; beyond 318 views it refuses"""
+    import pytest
+    from graspnet_amd import synthetic as S, weights as W
+    ref = W.prepare(S.make_state_dict(0), "cpu")
+    for v in (1, 60, 318):
+        pk = W.prepare(S.make_state_dict(0, num_view=v), "cpu", num_view=v)
+        for name in ("approach", "approach_split"):
+            assert [tuple(t.shape) for t in pk[name].w] == [tuple(t.shape) for t in ref[name].w], (v, name)
+            assert [tuple(t.shape) for t in pk[name].b] == [tuple(t.shape) for t in ref[name].b], (v, name)
+    with pytest.raises(NotImplementedError):
+        W.prepare(S.make_state_dict(0, num_view=319), "cpu", num_view=319)

@@ -137,6 +137,19 @@ def test_fps_cell_kernel_bit_exact(E, oracle, monkeypatch, n, m, variant, cell):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("n,m,cell", [(4097, 1, "16"), (5003, 2, "32"), (7919, 33, "16"), (16385, 600, "16"), (24577, 600, None),
+                                      (33333, 257, None), (65536, 100, None), (65537, 100, None), (131073, 64, None)])
+def test_fps_cell_kernel_odd_sizes(E, oracle, monkeypatch, n, m, cell):
+    """sizes around the cell kernel's layout boundaries (16 x 16 / 32 x 32 regions, 1 / 2 / 4 rows, the 65 536-point switch),
+    primes, one and two samples; sampled-with-replacement clouds (exact duplicates) on every other case"""
+    if cell is not None:
+        monkeypatch.setenv("GN_FPS_CELL", cell)
+    x = _cloud(1300 + n, 2, n, "surface" if n % 2 else "uniform")
+    want = oracle.furthest_point_sampling(x, m)
+    got = E.furthest_point_sampling(_dev(x), m).cpu()
+    assert torch.equal(got, want)
+
+
 def test_fps_cell_kernel_ties_and_skips(E, oracle, monkeypatch):
     """the adversarial cases of the register kernels on the cell kernel: every point at one of two tied locations (the
     reference's tree order decides), every point skipped (index 0 throughout), exact duplicates of the whole cloud"""

@@ -102,3 +102,31 @@ def test_bench_gpus_2_starts_its_own_ranks_strong():
     d = _self_launch(["--global-batch", "16"])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "strong" and d["config"]["batch_per_gpu"] == 8
     assert abs(d["value"] - 16 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
+
+
+def test_rccl_backend_runs_the_gather_collective_on_this_box():
+    """the N>1 runs use torch.distributed's "nccl" backend (= RCCL on ROCm); two ranks cannot share the one GPU of the test box
+    under RCCL, so this checks what can be checked here: the backend initialises (HSA_ENABLE_IPC_MODE_LEGACY=0 in the
+    environment), and the very collective GraspGatherer issues -- all_gather_into_tensor of the packed (B, M*17+1) buffer on a
+    side stream behind an event -- runs on it with a one-rank group and returns the rank's own lists"""
+    code = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(os.getcwd(), "graspnet-baseline_amd"))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+g = torch.rand(8, 1024, 17, device="cuda"); c = torch.randint(0, 1024, (8,), device="cuda", dtype=torch.int32)
+send = torch.empty((8, 1024 * 17 + 1), device="cuda"); send[:, :-1] = g.reshape(8, -1); send[:, -1] = c.view(torch.float32)
+side = torch.cuda.Stream(); ev = torch.cuda.Event(); ev.record()
+with torch.cuda.stream(side):
+    side.wait_event(ev)
+    recv = torch.empty_like(send)
+    dist.all_gather_into_tensor(recv, send)
+side.synchronize()
+assert torch.equal(recv, send)
+dist.barrier(); dist.destroy_process_group()
+print("rccl ok", dist.is_nccl_available())
+"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "rccl ok True" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])

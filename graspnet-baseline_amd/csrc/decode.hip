@@ -71,7 +71,43 @@ __global__ __launch_bounds__(1024) void pred_decode_kernel(const float *__restri
     if (s < m) {
       const float *f = feat + (size_t)s * ldf;
       keep = f[1] > f[0];  // argmax(objectness,0)==1  (graspnet.py:112-113)
-      if (na == 12 && vec16) {
+      if (na == 12 && vec16 && nd == 4) {
+        // the reference configuration: a (seed, depth) row is 48 floats = [score | angle cls | width | tolerance] x 12.  Two
+        // round trips for the whole seed instead of one per depth: the four depths' angle-class quarters (3 x 16 bytes each,
+        // all 12 loads in flight), then the three values each depth's arg-max picks (12 dword loads in flight) -- the walk
+        // that loaded every depth's 12 x 16 bytes in turn made this kernel 28 us, a chain of ~50 dependent dwords before it 45
+        using f32x4 = __attribute__((ext_vector_type(4))) float;
+        const float *hs = head + (size_t)s * 4 * hc;
+        f32x4 q[4][3];
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) q[d][i] = reinterpret_cast<const f32x4 *>(hs + d * hc + 12)[i];
+        int a4[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          int a = 0;
+          float av = q[d][0][0];
+#pragma unroll
+          for (int t = 1; t < 12; ++t) {  // graspnet.py:93 angle class per (seed, depth): first maximum
+            const float v = q[d][t >> 2][t & 3];
+            if (v > av) { av = v; a = t; }
+          }
+          a4[d] = a;
+        }
+        float sc4[4], wd4[4], tl4[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          sc4[d] = hs[d * hc + a4[d]];
+          wd4[d] = hs[d * hc + 24 + a4[d]];
+          tl4[d] = hs[d * hc + 36 + a4[d]];
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+          if (d == 0 || sc4[d] > score) {  // graspnet.py:103 depth class = argmax of the gathered score
+            score = sc4[d]; bd = d; ba = a4[d]; width = wd4[d]; tol = tl4[d];
+          }
+      } else if (na == 12 && vec16) {
         // the reference configuration: a (seed, depth) row is 48 floats = 12 x 16-byte loads, all requested before the
         // first compare (the scalar walk below chains ~50 dependent 4-byte loads per depth and made this kernel 45 us)
         using f32x4 = __attribute__((ext_vector_type(4))) float;

@@ -32,6 +32,9 @@
 namespace gn {
 namespace {
 
+#ifndef FC_ROWS_IN_FLIGHT
+#define FC_ROWS_IN_FLIGHT 4     // rows of 64 slots a wave requests before it waits (8: 3.436 vs 3.441 ms at n = 50 000, no gain)
+#endif
 constexpr int FC_XB = 2048;   // x histogram bins
 constexpr int FC_YB = 1024;   // y histogram bins per slab
 
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(1024) void fps_cell_kernel(const float *__restrict_
   // the build runs on all 16 waves; the chain keeps NWC of them (the others end before it): every wave that takes part in
   // a step pays ~110 instructions of bookkeeping whether or not one of its regions changed, and four waves share a SIMD
   constexpr int NT = 1024, NW = 16, R = S * S, RPW = R / NWC, ROW = 64 * RS, P = R * ROW, NTC = NWC * 64;
-  constexpr int UNR = 4 / RS;                        // regions fetched together: UNR * RS = 4 rows in flight
+  constexpr int UNR = FC_ROWS_IN_FLIGHT / RS;        // regions fetched together: UNR * RS rows in flight
   static_assert(S == 16 || S == 32, "16 x 16 or 32 x 32 regions");
   static_assert(RS == 1 || RS == 2 || RS == 4, "1, 2 or 4 rows of 64 slots per region");
   static_assert(RPW <= 64 && RPW * NWC == R && S % NWC == 0, "one owner lane per region");

@@ -70,3 +70,37 @@ def test_header_is_plain_c_and_links_against_the_library(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
     assert out.stdout.strip()
+
+
+def test_argument_checks_answer_before_any_launch():
+    """the status / gn_last_error convention on arguments the host can get wrong (no GPU needed: every check below fails
+    before the first launch): a view count beyond the packed kernel shape, a null layer pointer, a misaligned workspace,
+    nsample beyond the grid kernels' 64-lane register, grasps without counts"""
+    import ctypes
+    from graspnet_amd import _lib
+    lib = _lib.lib()
+    dummy = (ctypes.c_char * 4096)()
+    addr = (ctypes.addressof(dummy) + 255) & ~255                    # a 256-byte-aligned non-null pointer that is never read
+    w, o = _lib.Weights(), _lib.Outputs()
+    for f, _ in _lib.Outputs._fields_:
+        if f not in ("grasps", "counts", "fork_streams", "crop_uidx", "crop_ucount"):
+            v = getattr(o, f)
+            if hasattr(v, "__len__"):
+                for i in range(len(v)):
+                    v[i] = addr
+            else:
+                setattr(o, f, addr)
+
+    def forward(ws=addr):
+        return lib.gn_graspnet_forward(ctypes.byref(w), addr, 1, 4096, ws, ctypes.byref(o), _lib.STAGE_HOOK(), None, None)
+
+    w.num_view = 400
+    assert forward() == -1 and b"num_view" in lib.gn_last_error()
+    w.num_view = 0
+    assert forward() == -1 and b"weight or bias pointer" in lib.gn_last_error()          # all layer pointers are null
+    assert forward(addr + 4) == -1 and b"256-byte aligned" in lib.gn_last_error()
+    o.grasps = addr
+    assert forward() == -1 and b"grasps and counts" in lib.gn_last_error()
+    assert lib.gn_ball_query_grid(addr, addr, 1, 5000, 8, 0.04, 65, addr, None) == -1 and b"nsample <= 64" in lib.gn_last_error()
+    assert lib.gn_furthest_point_sampling(None, 1, 100, 10, None, addr, None, None, None, None) == -1
+    assert lib.gn_fps_workspace_bytes(8, 50000) >= 8 * 65536 * 20 and lib.gn_fps_workspace_bytes(8, 2048) == 0

@@ -158,7 +158,7 @@ extern "C" int gn_graspnet_forward(const gn_weights *wt, const float *cloud, int
                  o->top_view_rot && o->vp_features && o->head,
              "graspnet_forward: null output");
   GN_REQUIRE(!o->grasps == !o->counts, "graspnet_forward: grasps and counts go together");
-  GN_REQUIRE(wt->num_view >= 0 && wt->num_view <= 318, "graspnet_forward: num_view must be 1..318 (0 = 300), got %d", wt->num_view);
+  GN_REQUIRE(wt->num_view >= 0 && wt->num_view <= 318, "graspnet_forward: num_view must be 0..318 (0 = the default 300), got %d", wt->num_view);
   {   // every layer pointer of the weight set that will be used
     auto full = [](const gn_mlp_weights &m, int nl) {
       for (int i = 0; i < nl; ++i)
@@ -263,9 +263,12 @@ extern "C" int gn_graspnet_forward(const gn_weights *wt, const float *cloud, int
   if (fk) {
     hipStream_t main_s = as_stream(st), side_s = fk->side;
     gn_stream_t side = reinterpret_cast<gn_stream_t>(side_s);
+    bool side_open = false;      // the side stream holds work of this call that the caller's stream has not joined yet
+    auto forked = [&]() -> int {
     // side: grid build (needs the cloud only) beside the SA1 sampler
     GN_HIP(hipEventRecord(fk->ev[0], main_s), "event record");
     GN_HIP(hipStreamWaitEvent(side_s, fk->ev[0], 0), "stream wait");
+    side_open = true;
     if (w.grid) {
       GN_TRY(gn_grid_build(cloud, b, n, kSa[0].radius, w.grid, side));
       GN_HIP(hipEventRecord(fk->ev[1], side_s), "event record");
@@ -291,6 +294,17 @@ extern "C" int gn_graspnet_forward(const gn_weights *wt, const float *cloud, int
       GN_TRY(features(l, st));
     }
     GN_HIP(hipStreamWaitEvent(main_s, fk->ev[6], 0), "stream wait");       // the join: nothing is left on the side stream
+    side_open = false;
+    return GN_OK;
+    };
+    const int frc = forked();
+    if (frc != GN_OK) {
+      // a failed stage must not leave the side stream running (it writes o->sa_* and the workspace) nor, under hipGraph
+      // capture, an unjoined fork: best-effort join before the error goes back to the caller
+      if (side_open && hipEventRecord(fk->ev[7], side_s) == hipSuccess) (void)hipStreamWaitEvent(main_s, fk->ev[7], 0);
+      (void)hipGetLastError();
+      return frc;
+    }
   } else {
     // one grid over the input cloud serves SA1's ball query and CloudCrop's cylinder query
     if (w.grid) GN_STAGE("grid_build", gn_grid_build(cloud, b, n, kSa[0].radius, w.grid, st));

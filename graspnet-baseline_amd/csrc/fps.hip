@@ -476,9 +476,12 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
   {
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xyz), 0, n * 12, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < NPT; ++i) {      // reads past the cloud return 0 (buffer bounds check); such slots are never used
-      bxv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, t * 12, i * NT * 12, 0));
-      byv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, t * 12, i * NT * 12 + 4, 0));
+    for (int i = 0; i < NPT; ++i) {
+      // the WHOLE point offset goes in voffset: the buffer range check covers voffset + the immediate only (soffset is
+      // excluded from it), so a slot k = t + i*NT >= n reads 0 instead of memory behind the cloud; such slots are never used
+      const int off = (t + i * NT) * 12;
+      bxv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, off, 0, 0));
+      byv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, off, 4, 0));
     }
   }
   float xmn = INFINITY, xmx = -INFINITY, ymn = INFINITY, ymx = -INFINITY;
@@ -947,10 +950,21 @@ extern "C" size_t gn_fps_workspace_bytes(int b, int n) {
   const int Q = (n + bs - 1) / bs;
   const long need = (long)bs * Q;
   if (need <= 4096 && !gn::fps_cell_forced(n)) return 0;
-  if (need <= gn::kRegCapacity) return (size_t)b * gn::fps_cell_workspace_bytes_one(n, gn::fps_cell_forced(n));   // tie-tracking calls
+  const int forced = gn::fps_cell_forced(n);
+  if (need <= gn::kRegCapacity) {
+    // the region / spatial kernels of the model's own 20 000-point level never touch a workspace
+    const char *ve = getenv("GN_FPS_VARIANT");
+    const int variant = ve ? atoi(ve) : 4;
+    const bool region_band = need > 1024 * 16 && need <= 1024 * 20 && (variant == 4 || variant == 3);
+    if (region_band && !forced) return 0;
+    return (size_t)b * gn::fps_cell_workspace_bytes_one(n, forced);            // tie-tracking calls
+  }
   size_t one = (size_t)n * sizeof(float);                                       // any-n kernel: the reference's `temp`
   if (need <= 1024L * 64) one = 3 * 1024 * 64 * sizeof(float);                  // rank-ordered SoA copy (tier kernel)
-  if (gn::fps_cell_supports(n)) one = one > gn::fps_cell_workspace_bytes_one(n) ? one : gn::fps_cell_workspace_bytes_one(n);
+  if (gn::fps_cell_supports(n) || forced) {
+    const size_t cell = gn::fps_cell_workspace_bytes_one(n, forced);            // GN_FPS_CELL=16|32 strides by its own S
+    one = one > cell ? one : cell;
+  }
   return (size_t)b * one;
 }
 

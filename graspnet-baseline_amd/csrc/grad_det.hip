@@ -92,6 +92,22 @@ __global__ __launch_bounds__(256) void inv_order_kernel(const int32_t *__restric
       l[j + 1] = v;
     }
   }
+}
+
+// the long segments, in a launch of their own: its 64 KB of LDS would otherwise cap the common case above (every segment
+// <= 64 entries, no LDS at all) at two workgroups per CU.  A wave without a long segment leaves at once.
+__global__ __launch_bounds__(256) void inv_order_long_kernel(const int32_t *__restrict__ idx, int n, int ne,
+                                                             const int32_t *__restrict__ off, int32_t *__restrict__ list) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int a0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  if (a0 >= n) return;      // wave-uniform
+  const int a = a0 + lane;
+  const int32_t *o = off + (size_t)b * (n + 1);
+  int32_t *l = list + (size_t)b * ne;
+  const int lo = a < n ? o[a] : 0, hi = a < n ? o[a + 1] : 0;
+  const int s = hi - lo;
+  if (!__ballot(s > SORT_MAX)) return;
   // 64 < s <= WSORT_MAX: the wave sorts the segment in LDS (s log^2 s / 64 compare-exchange steps; the ballot rebuild
   // below costs ne / 64 steps per destination whatever s is: 2 048 at SA1's 2048 x 64 entries)
   __shared__ int s_sort[4][WSORT_MAX];
@@ -163,6 +179,8 @@ __global__ __launch_bounds__(256) void grad_sum_kernel(const float *__restrict__
   }
 }
 
+int seg_order(const int32_t *idx, int b, int n, int ne, const int32_t *off, int32_t *list, hipStream_t s);
+
 struct InvWs { int32_t *off, *cursor, *list; };
 
 static InvWs inv_carve(void *ws, int b, int n, long ne) {
@@ -188,10 +206,20 @@ static int invert(const int32_t *idx, int b, int n, long ne, void *workspace, In
     hipLaunchKernelGGL(inv_count_kernel, ge, dim3(256), 0, s, idx, n, (int)ne, w.off);
     hipLaunchKernelGGL(inv_scan_kernel, dim3(b), dim3(1024), 0, s, n, w.off);
     hipLaunchKernelGGL(inv_fill_kernel, ge, dim3(256), 0, s, idx, n, (int)ne, w.off, w.cursor, w.list);
-    dim3 go((unsigned)((n + 255) / 256), b);
-    hipLaunchKernelGGL(inv_order_kernel, go, dim3(256), 0, s, idx, n, (int)ne, w.off, w.list);
+    if (int rc = seg_order(idx, b, n, (int)ne, w.off, w.list, s)) return rc;
   }
   *out = w;
+  return GN_OK;
+}
+
+// off (b, n+1) / list (b, ne) as the inversion leaves them after its fill pass, idx (b, ne) the destination of every entry:
+// puts each destination's segment of `list` in ascending order (shared with the voxel down-sample of post.hip)
+int seg_order(const int32_t *idx, int b, int n, int ne, const int32_t *off, int32_t *list, hipStream_t s) {
+  if (b <= 0 || n <= 0 || ne <= 0) return GN_OK;
+  dim3 go((unsigned)((n + 255) / 256), b);
+  hipLaunchKernelGGL(inv_order_kernel, go, dim3(256), 0, s, idx, n, ne, off, list);
+  if (ne > SORT_MAX) hipLaunchKernelGGL(inv_order_long_kernel, go, dim3(256), 0, s, idx, n, ne, off, list);
+  GN_CHECK_LAUNCH("seg_order");
   return GN_OK;
 }
 

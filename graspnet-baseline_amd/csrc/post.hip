@@ -37,21 +37,39 @@ __global__ __launch_bounds__(256) void depth_to_cloud_kernel(const uint16_t *__r
 }
 
 // ------------------------------------------------------------------------------------------------
-// voxel down-sample: hash grid with 64-bit keys, double sums
-// workspace: [0] int counter, [1] int error flag, [2..7] double min bound (3) ... then the table
+// voxel down-sample, a whole batch of clouds per call, no host read, DETERMINISTIC:
+//   * which voxel a point falls in, a voxel's member count and its lowest member index are integer facts (CAS on the
+//     64-bit key, integer atomics) -- the same whatever order the hardware retires them in;
+//   * the output ORDER is the order of first appearance (voxels sorted by their lowest member index): a prefix scan over
+//     the points' "I am my voxel's first member" flags, no ticket;
+//   * a voxel's mean adds its members in ASCENDING index order (the ticket-filled member lists are put in order by the
+//     sorted-segment machinery of grad_det.hip), float64 -- the order numpy's sequential np.add.at uses, so the means are
+//     bit-identical to oracle/post_oracle.py and to themselves from run to run (float64 atomics in arrival order, the
+//     round-3 form, were neither).
+// workspace per call (b clouds of n points, S = table slots per cloud):
+//   keys u64 [b][S] | first u32 [b][S]            <- one 0xff memset
+//   cnt i32 [b][S] | cursor i32 [b][S] | hdr [b]  <- one zero memset
+//   srank i32 [b][S] | pslot i32 [b][n] | vidx i32 [b][n] | off i32 [b][n+1] | list i32 [b][n]
 // ------------------------------------------------------------------------------------------------
 struct VoxelHeader {
-  int count;
-  int error;
   double minb[3];
+  int pad[2];
 };
 
-__global__ __launch_bounds__(1024) void voxel_minbound_kernel(const float *__restrict__ pts, int n,
-                                                              VoxelHeader *__restrict__ hdr) {
+__device__ __forceinline__ bool finite3(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }
+
+// one workgroup per cloud: min bound over the valid, finite points
+__global__ __launch_bounds__(1024) void voxel_minbound_kernel(const float *__restrict__ pts, const int32_t *__restrict__ n_valid,
+                                                              int n, VoxelHeader *__restrict__ hdr, int32_t *__restrict__ status) {
   __shared__ float s[3][16];
+  const int b = blockIdx.x;
+  pts += (size_t)b * n * 3;
+  const int nv = n_valid ? min(max(n_valid[b], 0), n) : n;
   float m[3] = {INFINITY, INFINITY, INFINITY};
-  for (int i = threadIdx.x; i < n; i += 1024)
-    for (int a = 0; a < 3; ++a) m[a] = fminf(m[a], pts[i * 3 + a]);
+  for (int i = threadIdx.x; i < nv; i += 1024) {
+    const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+    if (finite3(x, y, z)) { m[0] = fminf(m[0], x); m[1] = fminf(m[1], y); m[2] = fminf(m[2], z); }
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int a = 0; a < 3; ++a) {
     const float v = -wave_max(-m[a]);
@@ -61,8 +79,8 @@ __global__ __launch_bounds__(1024) void voxel_minbound_kernel(const float *__res
   if (threadIdx.x < 3) {
     float v = s[threadIdx.x][0];
     for (int wv = 1; wv < 16; ++wv) v = fminf(v, s[threadIdx.x][wv]);
-    hdr->minb[threadIdx.x] = (double)v;
-    if (threadIdx.x == 0) { hdr->count = 0; hdr->error = 0; }
+    hdr[b].minb[threadIdx.x] = (double)v;
+    if (threadIdx.x == 0) status[b] = 0;
   }
 }
 
@@ -73,56 +91,162 @@ __device__ __forceinline__ unsigned long long hash64(unsigned long long k) {
 
 constexpr unsigned long long VOXEL_EMPTY = ~0ULL;
 
-__global__ __launch_bounds__(256) void voxel_insert_kernel(const float *__restrict__ pts, int n, double voxel,
-                                                           VoxelHeader *__restrict__ hdr,
-                                                           unsigned long long *__restrict__ keys,
-                                                           double *__restrict__ sums, int *__restrict__ cnts,
-                                                           unsigned table_mask) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+// one thread per point: its voxel's table slot; the slot's member count and lowest member index
+__global__ __launch_bounds__(256) void voxel_insert_kernel(const float *__restrict__ pts, const int32_t *__restrict__ n_valid,
+                                                           int n, double voxel, const VoxelHeader *__restrict__ hdr,
+                                                           unsigned long long *__restrict__ keys, unsigned *__restrict__ first,
+                                                           int *__restrict__ cnt, int32_t *__restrict__ pslot,
+                                                           unsigned table_mask, int32_t *__restrict__ status) {
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
   if (i >= n) return;
+  const size_t tb = (size_t)b * (table_mask + 1);
+  pslot += (size_t)b * n;
+  const int nv = n_valid ? min(max(n_valid[b], 0), n) : n;
+  const float *p3 = pts + ((size_t)b * n + i) * 3;
+  const float fx = p3[0], fy = p3[1], fz = p3[2];
+  if (i >= nv || !finite3(fx, fy, fz)) { pslot[i] = -1; return; }     // padding / non-finite points belong to no voxel
+  const double p[3] = {(double)fx, (double)fy, (double)fz};
   unsigned long long key = 0;
-  double p[3];
   for (int a = 0; a < 3; ++a) {
-    p[a] = (double)pts[i * 3 + a];
-    const double origin = hdr->minb[a] - voxel * 0.5;
-    const double ref = (p[a] - origin) / voxel;
-    const long long vi = (long long)floor(ref);
-    if (vi < 0 || vi >= (1LL << 21)) { atomicExch(&hdr->error, 1); return; }
+    const double origin = hdr[b].minb[a] - voxel * 0.5;
+    const long long vi = (long long)floor((p[a] - origin) / voxel);
+    if (vi < 0 || vi >= (1LL << 21)) { atomicExch(&status[b], 1); pslot[i] = -1; return; }
     key |= (unsigned long long)vi << (21 * a);
   }
   unsigned slot = (unsigned)hash64(key) & table_mask;
   for (unsigned probe = 0; probe <= table_mask; ++probe) {
-    const unsigned long long prev = atomicCAS(&keys[slot], VOXEL_EMPTY, key);
+    const unsigned long long prev = atomicCAS(&keys[tb + slot], VOXEL_EMPTY, key);
     if (prev == VOXEL_EMPTY || prev == key) {
-      atomicAdd(&sums[slot * 3 + 0], p[0]);
-      atomicAdd(&sums[slot * 3 + 1], p[1]);
-      atomicAdd(&sums[slot * 3 + 2], p[2]);
-      atomicAdd(&cnts[slot], 1);
+      atomicMin(&first[tb + slot], (unsigned)i);
+      atomicAdd(&cnt[tb + slot], 1);
+      pslot[i] = (int)slot;
       return;
     }
     slot = (slot + 1) & table_mask;
   }
-  atomicExch(&hdr->error, 2);
+  atomicExch(&status[b], 2);
+  pslot[i] = -1;
 }
 
-__global__ __launch_bounds__(256) void voxel_emit_kernel(const double *__restrict__ sums, const int *__restrict__ cnts,
-                                                         unsigned nslots, VoxelHeader *__restrict__ hdr,
-                                                         double *__restrict__ out) {
-  const unsigned s = blockIdx.x * 256 + threadIdx.x;
-  if (s >= nslots) return;
-  const int c = cnts[s];
-  if (c > 0) {
-    const int o = atomicAdd(&hdr->count, 1);
-    out[o * 3 + 0] = sums[s * 3 + 0] / (double)c;
-    out[o * 3 + 1] = sums[s * 3 + 1] / (double)c;
-    out[o * 3 + 2] = sums[s * 3 + 2] / (double)c;
+// one workgroup per cloud: voxels ranked by their lowest member index (a prefix count of the leader flags) and, in the
+// same pass, the member-list offsets in that order (a prefix sum of the leaders' member counts)
+__global__ __launch_bounds__(1024) void voxel_rank_kernel(const int32_t *__restrict__ pslot, const unsigned *__restrict__ first,
+                                                          const int *__restrict__ cnt, int n, unsigned nslots,
+                                                          int32_t *__restrict__ srank, int32_t *__restrict__ off,
+                                                          int32_t *__restrict__ out_counts) {
+  __shared__ int s_f[16], s_c[16];
+  __shared__ int s_cf, s_cc;
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  pslot += (size_t)b * n;
+  first += (size_t)b * nslots; cnt += (size_t)b * nslots; srank += (size_t)b * nslots;
+  off += (size_t)b * (n + 1);
+  if (t == 0) { s_cf = 0; s_cc = 0; }
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + t;
+    const int slot = i < n ? pslot[i] : -1;
+    const bool leader = slot >= 0 && first[slot] == (unsigned)i;
+    const int f = leader ? 1 : 0, c = leader ? cnt[slot] : 0;
+    int inf = f, inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int uf = __shfl_up(inf, o), uc = __shfl_up(inc, o);
+      if (lane >= o) { inf += uf; inc += uc; }
+    }
+    if (lane == 63) { s_f[wave] = inf; s_c[wave] = inc; }
+    __syncthreads();
+    int wf = s_cf, wc = s_cc;
+    for (int w = 0; w < wave; ++w) { wf += s_f[w]; wc += s_c[w]; }
+    if (leader) {
+      const int pos = wf + inf - 1;
+      srank[slot] = pos;
+      off[pos] = wc + inc - c;
+    }
+    __syncthreads();
+    if (t == 1023) { s_cf = wf + inf; s_cc = wc + inc; }
+    __syncthreads();
   }
+  const int nv = s_cf, total = s_cc;
+  for (int a = nv + t; a <= n; a += 1024) off[a] = total;
+  if (t == 0) out_counts[b] = nv;
+}
+
+// member lists: every point takes a ticket in its voxel's segment (arbitrary order; seg_order() sorts the segments)
+__global__ __launch_bounds__(256) void voxel_fill_kernel(const int32_t *__restrict__ pslot, const int32_t *__restrict__ srank,
+                                                         const int32_t *__restrict__ off, int *__restrict__ cursor, int n,
+                                                         unsigned nslots, int32_t *__restrict__ vidx,
+                                                         int32_t *__restrict__ list) {
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (i >= n) return;
+  const int slot = pslot[(size_t)b * n + i];
+  int v = -1;
+  if (slot >= 0) {
+    v = srank[(size_t)b * nslots + slot];
+    const int pos = off[(size_t)b * (n + 1) + v] + atomicAdd(&cursor[(size_t)b * nslots + slot], 1);
+    list[(size_t)b * n + pos] = i;
+  }
+  vidx[(size_t)b * n + i] = v;
+}
+
+// one thread per output row: the voxel's members added in ascending index order, float64, then the mean; rows past
+// the cloud's voxel count are zero
+__global__ __launch_bounds__(256) void voxel_mean_kernel(const float *__restrict__ pts, const int32_t *__restrict__ off,
+                                                         const int32_t *__restrict__ list, const int32_t *__restrict__ counts,
+                                                         int n, double *__restrict__ out) {
+  const int a = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (a >= n) return;
+  double sx = 0.0, sy = 0.0, sz = 0.0;
+  if (a < counts[b]) {
+    const int lo = off[(size_t)b * (n + 1) + a], hi = off[(size_t)b * (n + 1) + a + 1];
+    const float *p = pts + (size_t)b * n * 3;
+    const int32_t *l = list + (size_t)b * n;
+    for (int t = lo; t < hi; ++t) {
+      const int e = l[t];
+      sx += (double)p[e * 3]; sy += (double)p[e * 3 + 1]; sz += (double)p[e * 3 + 2];
+    }
+    const double c = (double)(hi - lo);
+    sx /= c; sy /= c; sz /= c;
+  }
+  double *o = out + ((size_t)b * n + a) * 3;
+  o[0] = sx; o[1] = sy; o[2] = sz;
 }
 
 static unsigned voxel_slots(int n) {
   unsigned s = 1024;
   while (s < 2u * (unsigned)n) s <<= 1;
   return s;
+}
+
+struct VoxelWs {
+  unsigned long long *keys;
+  unsigned *first;
+  int *cnt, *cursor;
+  VoxelHeader *hdr;
+  int32_t *srank, *pslot, *vidx, *off, *list;
+  size_t ff_bytes, zero_bytes, bytes;
+};
+
+static VoxelWs voxel_carve(void *base, int b, int n) {
+  const size_t S = voxel_slots(n), B = (size_t)b, N = (size_t)n;
+  char *p = static_cast<char *>(base);
+  size_t o = 0;
+  auto take = [&](size_t bytes) { char *q = p ? p + o : nullptr; o += (bytes + 255) & ~(size_t)255; return q; };
+  VoxelWs w;
+  w.keys = (unsigned long long *)take(B * S * 8 + B * S * 4);
+  w.first = p ? (unsigned *)(w.keys + B * S) : nullptr;
+  w.ff_bytes = B * S * 12;
+  const size_t z0 = o;
+  w.cnt = (int *)take(B * S * 4);
+  w.cursor = (int *)take(B * S * 4);
+  w.hdr = (VoxelHeader *)take(B * sizeof(VoxelHeader));
+  w.zero_bytes = o - z0;
+  w.srank = (int32_t *)take(B * S * 4);
+  w.pslot = (int32_t *)take(B * N * 4);
+  w.vidx = (int32_t *)take(B * N * 4);
+  w.off = (int32_t *)take(B * (N + 1) * 4);
+  w.list = (int32_t *)take(B * N * 4);
+  w.bytes = o;
+  return w;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -134,7 +258,8 @@ struct CollisionParams {
   double collision_thresh, empty_thresh;
 };
 
-__global__ __launch_bounds__(256) void collision_kernel(const double *__restrict__ scene, const int *__restrict__ np_ptr,
+__global__ __launch_bounds__(256) void collision_kernel(const double *__restrict__ scene, size_t scene_stride,
+                                                        const int *__restrict__ np_ptr, int np_stride,
                                                         int np_fixed, const float *__restrict__ grasps, int ldg,
                                                         const int32_t *__restrict__ counts, int mpad,
                                                         CollisionParams P, uint8_t *__restrict__ collision_mask,
@@ -153,7 +278,9 @@ __global__ __launch_bounds__(256) void collision_kernel(const double *__restrict
   }
   if (threadIdx.x < 6) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  const int np = np_ptr ? *np_ptr : np_fixed;
+  // scene b's own down-sampled cloud (scene_stride doubles apart; 0 = one scene for the whole batch) and point count
+  scene += (size_t)b * scene_stride;
+  const int np = np_ptr ? min(np_ptr[(size_t)b * np_stride], np_fixed) : np_fixed;
   const float *gr = grasps + orow * ldg;
   const float width = gr[1], height = gr[2], depth = gr[3];
   double R[9], T[3];
@@ -347,49 +474,69 @@ extern "C" int gn_depth_to_cloud(const uint16_t *depth, int h, int w, double fx,
   return GN_OK;
 }
 
+extern "C" size_t gn_voxel_batched_workspace_bytes(int b, int n) {
+  if (b <= 0 || n <= 0) return 0;
+  return voxel_carve(nullptr, b, n).bytes;
+}
+
+extern "C" int gn_voxel_down_sample_batched(const float *points, const int32_t *n_valid, int b, int n, double voxel_size,
+                                            void *workspace, double *out, int32_t *out_counts, int32_t *status,
+                                            gn_stream_t stream) {
+  GN_REQUIRE(b >= 0 && n >= 0 && voxel_size > 0.0, "voxel_down_sample: bad sizes");
+  if (b == 0) return GN_OK;
+  GN_REQUIRE(out_counts && status, "voxel_down_sample: null pointer");
+  GN_REQUIRE(b <= 65535, "voxel_down_sample: batch > 65535 unsupported");
+  hipStream_t s = as_stream(stream);
+  if (n == 0) {
+    if (hipMemsetAsync(out_counts, 0, sizeof(int32_t) * (size_t)b, s) != hipSuccess ||
+        hipMemsetAsync(status, 0, sizeof(int32_t) * (size_t)b, s) != hipSuccess) {
+      set_error("voxel_down_sample: memset failed");
+      return GN_ERR_LAUNCH;
+    }
+    return GN_OK;
+  }
+  GN_REQUIRE(points && workspace && out, "voxel_down_sample: null pointer");
+  GN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "voxel_down_sample: workspace must be 256-byte aligned");
+  const VoxelWs w = voxel_carve(workspace, b, n);
+  const unsigned slots = voxel_slots(n);
+  if (hipMemsetAsync(w.keys, 0xff, w.ff_bytes, s) != hipSuccess ||
+      hipMemsetAsync(w.cnt, 0, w.zero_bytes, s) != hipSuccess) {
+    set_error("voxel_down_sample: memset failed");
+    return GN_ERR_LAUNCH;
+  }
+  const dim3 gp((n + 255) / 256, b);
+  hipLaunchKernelGGL(voxel_minbound_kernel, dim3(b), dim3(1024), 0, s, points, n_valid, n, w.hdr, status);
+  hipLaunchKernelGGL(voxel_insert_kernel, gp, dim3(256), 0, s, points, n_valid, n, voxel_size, w.hdr, w.keys, w.first, w.cnt,
+                     w.pslot, slots - 1, status);
+  hipLaunchKernelGGL(voxel_rank_kernel, dim3(b), dim3(1024), 0, s, w.pslot, w.first, w.cnt, n, slots, w.srank, w.off, out_counts);
+  hipLaunchKernelGGL(voxel_fill_kernel, gp, dim3(256), 0, s, w.pslot, w.srank, w.off, w.cursor, n, slots, w.vidx, w.list);
+  GN_CHECK_LAUNCH("voxel_down_sample");
+  if (int rc = seg_order(w.vidx, b, n, n, w.off, w.list, s)) return rc;
+  hipLaunchKernelGGL(voxel_mean_kernel, gp, dim3(256), 0, s, points, w.off, w.list, out_counts, n, out);
+  GN_CHECK_LAUNCH("voxel_down_sample");
+  return GN_OK;
+}
+
+// the one-cloud form: workspace = [status (256 B) | the batched workspace]
 extern "C" size_t gn_voxel_workspace_bytes(int n) {
   if (n <= 0) return 0;
-  const size_t slots = voxel_slots(n);
-  return 64 + slots * (8 + 24 + 4);
+  return 256 + gn_voxel_batched_workspace_bytes(1, n);
 }
 
 extern "C" int gn_voxel_down_sample(const float *points, int n, double voxel_size, void *workspace, double *out,
                                     int32_t *out_count, gn_stream_t stream) {
   GN_REQUIRE(n >= 0 && voxel_size > 0.0, "voxel_down_sample: bad sizes");
   GN_REQUIRE(points && workspace && out && out_count, "voxel_down_sample: null pointer");
-  hipStream_t s = as_stream(stream);
-  if (n == 0) {
-    if (hipMemsetAsync(out_count, 0, sizeof(int32_t), s) != hipSuccess) return GN_ERR_LAUNCH;
-    return GN_OK;
-  }
-  const unsigned slots = voxel_slots(n);
-  char *ws = (char *)workspace;
-  VoxelHeader *hdr = (VoxelHeader *)ws;
-  unsigned long long *keys = (unsigned long long *)(ws + 64);
-  double *sums = (double *)(ws + 64 + (size_t)slots * 8);
-  int *cnts = (int *)(ws + 64 + (size_t)slots * 32);
-  if (hipMemsetAsync(keys, 0xff, (size_t)slots * 8, s) != hipSuccess ||
-      hipMemsetAsync(sums, 0, (size_t)slots * 28, s) != hipSuccess) {
-    set_error("voxel_down_sample: memset failed");
-    return GN_ERR_LAUNCH;
-  }
-  hipLaunchKernelGGL(voxel_minbound_kernel, dim3(1), dim3(1024), 0, s, points, n, hdr);
-  hipLaunchKernelGGL(voxel_insert_kernel, dim3((n + 255) / 256), dim3(256), 0, s, points, n, voxel_size, hdr, keys, sums,
-                     cnts, slots - 1);
-  hipLaunchKernelGGL(voxel_emit_kernel, dim3((slots + 255) / 256), dim3(256), 0, s, sums, cnts, slots, hdr, out);
-  if (hipMemcpyAsync(out_count, &hdr->count, sizeof(int32_t), hipMemcpyDeviceToDevice, s) != hipSuccess) {
-    set_error("voxel_down_sample: count copy failed");
-    return GN_ERR_LAUNCH;
-  }
-  GN_CHECK_LAUNCH("voxel_down_sample");
-  return GN_OK;
+  return gn_voxel_down_sample_batched(points, nullptr, 1, n, voxel_size, static_cast<char *>(workspace) + 256, out, out_count,
+                                      static_cast<int32_t *>(workspace), stream);
 }
 
-extern "C" int gn_collision_detect(const double *scene_points, const int32_t *np_dev, int np, const float *grasps,
-                                   const int32_t *counts, int b, int mpad, float approach_dist, double collision_thresh,
-                                   double empty_thresh, float voxel_size, float finger_width, float finger_length,
-                                   uint8_t *collision_mask, uint8_t *empty_mask, float *ious, gn_stream_t stream) {
-  GN_REQUIRE(b >= 0 && mpad >= 0 && (np_dev || np >= 0), "collision_detect: bad sizes");
+static int collision_launch(const double *scene_points, size_t scene_stride, const int32_t *np_dev, int np_stride, int np,
+                            const float *grasps, const int32_t *counts, int b, int mpad, float approach_dist,
+                            double collision_thresh, double empty_thresh, float voxel_size, float finger_width,
+                            float finger_length, uint8_t *collision_mask, uint8_t *empty_mask, float *ious,
+                            gn_stream_t stream) {
+  GN_REQUIRE(b >= 0 && mpad >= 0 && np >= 0, "collision_detect: bad sizes");
   if (b == 0 || mpad == 0) return GN_OK;
   GN_REQUIRE(scene_points && grasps && collision_mask, "collision_detect: null pointer");
   GN_REQUIRE(b <= 65535, "collision_detect: batch > 65535 unsupported");
@@ -400,10 +547,31 @@ extern "C" int gn_collision_detect(const double *scene_points, const int32_t *np
   P.approach_dist = approach_dist > finger_width ? approach_dist : finger_width;   // collision_detector.py:69
   P.collision_thresh = collision_thresh;
   P.empty_thresh = empty_thresh;
-  hipLaunchKernelGGL(collision_kernel, dim3(mpad, b), dim3(256), 0, as_stream(stream), scene_points, np_dev, np, grasps,
-                     17, counts, mpad, P, collision_mask, empty_mask, ious);
+  hipLaunchKernelGGL(collision_kernel, dim3(mpad, b), dim3(256), 0, as_stream(stream), scene_points, scene_stride, np_dev,
+                     np_stride, np, grasps, 17, counts, mpad, P, collision_mask, empty_mask, ious);
   GN_CHECK_LAUNCH("collision_detect");
   return GN_OK;
+}
+
+extern "C" int gn_collision_detect(const double *scene_points, const int32_t *np_dev, int np, const float *grasps,
+                                   const int32_t *counts, int b, int mpad, float approach_dist, double collision_thresh,
+                                   double empty_thresh, float voxel_size, float finger_width, float finger_length,
+                                   uint8_t *collision_mask, uint8_t *empty_mask, float *ious, gn_stream_t stream) {
+  // np_dev (one device int, e.g. gn_voxel_down_sample's out_count) bounds the scene when given; np is then its capacity
+  GN_REQUIRE(np_dev || np >= 0, "collision_detect: bad sizes");
+  return collision_launch(scene_points, 0, np_dev, 0, np_dev && np <= 0 ? 0x7fffffff : np, grasps, counts, b, mpad,
+                          approach_dist, collision_thresh, empty_thresh, voxel_size, finger_width, finger_length,
+                          collision_mask, empty_mask, ious, stream);
+}
+
+extern "C" int gn_collision_detect_batched(const double *scene_points, int np_max, const int32_t *np_dev, const float *grasps,
+                                           const int32_t *counts, int b, int mpad, float approach_dist,
+                                           double collision_thresh, double empty_thresh, float voxel_size, float finger_width,
+                                           float finger_length, uint8_t *collision_mask, uint8_t *empty_mask, float *ious,
+                                           gn_stream_t stream) {
+  return collision_launch(scene_points, (size_t)(np_max > 0 ? np_max : 0) * 3, np_dev, 1, np_max, grasps, counts, b, mpad,
+                          approach_dist, collision_thresh, empty_thresh, voxel_size, finger_width, finger_length,
+                          collision_mask, empty_mask, ious, stream);
 }
 
 extern "C" size_t gn_grasp_nms_workspace_bytes(int b) {

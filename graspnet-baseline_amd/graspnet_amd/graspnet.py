@@ -452,31 +452,46 @@ class GraphedGraspNet:
     the returned end_points / grasps / counts are the graph's static output tensors (overwritten by the
     next call).  Nothing in the C ABI allocates or synchronises, which is what makes the capture legal."""
 
-    def __init__(self, net, batch, points, warmup=2, fork_streams=True):
+    def __init__(self, net, batch, points, warmup=2, fork_streams=True, post=None):
+        """post: None, or a dict of postprocess.grasp_pipeline() keyword arguments -- the graph then also holds the steps every
+        caller of the reference runs on the host after pred_decode (voxel down-sample of each scene, collision filter, sort +
+        NMS: test.py:88-96, demo_pointcloud.py:228-249) and a call returns
+        (end_points, grasps, counts, final_rows (B,M,17), kept (B,), collision_mask (B,M))."""
+        from . import postprocess
         self.net = net
+        self.post = None if post is None else dict(post)
         dev = net.device
         self.static_in = torch.zeros((batch, points, 3), dtype=torch.float32, device=dev)
+        # a cloud of all-equal points is a legal input but not a typical one: warm up on spread-out coordinates
+        self.static_in.uniform_(-0.3, 0.3)
+        self.static_in[..., 2] += 0.5
+
+        def run():
+            ep = net({"point_clouds": self.static_in})
+            g, c = net.decode_padded(ep)
+            tail = postprocess.grasp_pipeline(self.static_in, g, c, **self.post) if self.post is not None else ()
+            return (ep, g, c) + tuple(tail)
+
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(warmup):       # first calls set kernel attributes / fill allocator pools
-                ep = net({"point_clouds": self.static_in})
-                net.decode_padded(ep)
+                run()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         fork, net.fork = net.fork, fork_streams      # static edges inside the graph: the side stream is a steady gain here
         try:
             with torch.cuda.graph(self.graph):
-                self.end_points = net({"point_clouds": self.static_in})
-                self.grasps, self.counts = net.decode_padded(self.end_points)
+                self.outputs = run()
         finally:
             net.fork = fork
+        self.end_points, self.grasps, self.counts = self.outputs[:3]
 
     def __call__(self, point_clouds):
         self.static_in.copy_(point_clouds[..., 0:3], non_blocking=True)
         self.graph.replay()
-        return self.end_points, self.grasps, self.counts
+        return self.outputs
 
 
 class PipelinedGraspNet:

@@ -33,24 +33,93 @@ def depth_to_cloud(depth, fx, fy, cx, cy, factor_depth, pix_idx):
     return out
 
 
-def voxel_down_sample(points, voxel_size):
-    """(N,3) f32 CUDA -> (Nv,3) f64 CUDA voxel means (one host sync for Nv)."""
+def voxel_down_sample_batched(points, voxel_size, n_valid=None, check=False):
+    """(B,N,3) f32 CUDA clouds -> (means (B,N,3) f64 padded with zero rows, counts (B,) i32, status (B,) i32), all on the
+    device, no host read (hipGraph-capturable).  Voxels come out in order of first appearance, every mean adds its members
+    in ascending index order: run-to-run bit-identical.  n_valid (B,) i32: points past it are padding.
+    check=True reads `status` back (one sync) and raises on a grid that exceeds 2^21 cells per axis."""
     if not points.is_cuda:
         raise RuntimeError("CPU not supported")
+    if points.dim() != 3 or points.size(-1) != 3:
+        raise RuntimeError("points must be (B,N,3)")
     points = points.to(torch.float32).contiguous()
-    n = points.shape[0]
+    B, n = points.shape[0], points.shape[1]
+    dev = points.device
     lib = L.lib()
-    ws = torch.empty((lib.gn_voxel_workspace_bytes(n),), dtype=torch.uint8, device=points.device)
-    out = torch.empty((max(n, 1), 3), dtype=torch.float64, device=points.device)
-    cnt = torch.zeros((1,), dtype=torch.int32, device=points.device)
-    with torch.cuda.device(points.device):
-        L.check(lib.gn_voxel_down_sample(points.data_ptr(), n, float(voxel_size), ws.data_ptr(), out.data_ptr(),
-                                         cnt.data_ptr(), _stream(points)), "voxel_down_sample")
-    err = ws[4:8].view(torch.int32)
-    nv, e = int(cnt.item()), int(err.item())
+    ws = torch.empty((max(lib.gn_voxel_batched_workspace_bytes(B, n), 256),), dtype=torch.uint8, device=dev)
+    out = torch.empty((B, n, 3), dtype=torch.float64, device=dev)
+    cnt = torch.empty((B,), dtype=torch.int32, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    nv = None if n_valid is None else n_valid.to(device=dev, dtype=torch.int32).contiguous()
+    with torch.cuda.device(dev):
+        L.check(lib.gn_voxel_down_sample_batched(points.data_ptr(), L.ptr(nv), B, n, float(voxel_size), ws.data_ptr(),
+                                                 out.data_ptr(), cnt.data_ptr(), status.data_ptr(), _stream(points)),
+                "voxel_down_sample")
+    if check:
+        e = int(status.max().item()) if B else 0
+        if e:
+            raise RuntimeError("voxel_down_sample: voxel grid exceeds 2^21 cells per axis or table overflow (code %d)" % e)
+    return out, cnt, status
+
+
+def voxel_down_sample(points, voxel_size):
+    """(N,3) f32 CUDA -> (Nv,3) f64 CUDA voxel means in order of first appearance (one host sync for Nv, as open3d's
+    call is synchronous too)."""
+    if not points.is_cuda:
+        raise RuntimeError("CPU not supported")
+    out, cnt, status = voxel_down_sample_batched(points.reshape(1, -1, 3), voxel_size)
+    nv, e = cnt.cpu().tolist()[0], status.cpu().tolist()[0]
     if e:
         raise RuntimeError("voxel_down_sample: voxel grid exceeds 2^21 cells per axis or table overflow (code %d)" % e)
-    return out[:nv]
+    return out[0, :nv]
+
+
+def _detect_outputs(B, M, dev, return_empty_grasp, return_ious):
+    cm = torch.empty((B, M), dtype=torch.uint8, device=dev)
+    em = torch.empty((B, M), dtype=torch.uint8, device=dev) if return_empty_grasp else None
+    io = torch.empty((B, M, 5), dtype=torch.float32, device=dev) if return_ious else None
+    return cm, em, io
+
+
+def _detect_result(cm, em, io):
+    ret = [cm.view(torch.bool)]
+    if em is not None:
+        ret.append(em.view(torch.bool))
+    if io is not None:
+        ret.append(io)
+    return ret[0] if len(ret) == 1 else ret
+
+
+class BatchedCollisionDetector:
+    """test.py:88-96 builds one ModelFreeCollisionDetector per scene of the batch and copies the grasps to the host first;
+    this is the same arithmetic for the whole batch in two sequences of launches with nothing read back: every scene's cloud
+    is voxel-down-sampled at construction (padded (B,N,3) f64 + per-scene counts on the device), detect_padded() checks the
+    padded grasp rows of scene b against scene b's points."""
+
+    def __init__(self, clouds, voxel_size=0.005, n_valid=None):
+        self.finger_width = 0.01          # collision_detector.py:29-30
+        self.finger_length = 0.06
+        self.voxel_size = voxel_size
+        self.scene_points, self.scene_counts, self.status = voxel_down_sample_batched(clouds, voxel_size, n_valid)
+
+    def detect_padded(self, grasps, counts=None, approach_dist=0.03, collision_thresh=0.05, return_empty_grasp=False,
+                      empty_thresh=0.01, return_ious=False):
+        if not grasps.is_cuda:
+            raise RuntimeError("CPU not supported")
+        grasps = grasps.contiguous()
+        B, M = grasps.shape[0], grasps.shape[1]
+        if B != self.scene_points.shape[0]:
+            raise RuntimeError("grasps hold %d scenes, the detector %d" % (B, self.scene_points.shape[0]))
+        dev = grasps.device
+        cm, em, io = _detect_outputs(B, M, dev, return_empty_grasp, return_ious)
+        with torch.cuda.device(dev):
+            L.check(L.lib().gn_collision_detect_batched(self.scene_points.data_ptr(), self.scene_points.shape[1],
+                                                        self.scene_counts.data_ptr(), grasps.data_ptr(), L.ptr(counts), B, M,
+                                                        float(approach_dist), float(collision_thresh), float(empty_thresh),
+                                                        float(self.voxel_size), self.finger_width, self.finger_length,
+                                                        cm.data_ptr(), L.ptr(em), L.ptr(io), _stream(grasps)),
+                    "collision_detect")
+        return _detect_result(cm, em, io)
 
 
 class ModelFreeCollisionDetector:
@@ -66,27 +135,21 @@ class ModelFreeCollisionDetector:
 
     def detect_padded(self, grasps, counts=None, approach_dist=0.03, collision_thresh=0.05, return_empty_grasp=False,
                       empty_thresh=0.01, return_ious=False):
-        """grasps (B,M,17) f32 CUDA, counts (B,) i32 or None -> collision mask (B,M) bool [, empty (B,M) bool][, ious (B,M,5)]"""
+        """grasps (B,M,17) f32 CUDA, counts (B,) i32 or None -> collision mask (B,M) bool [, empty (B,M) bool][, ious (B,M,5)]
+        every scene of `grasps` is checked against THIS detector's one scene (the reference's object holds one scene)"""
         if not grasps.is_cuda:
             raise RuntimeError("CPU not supported")
         grasps = grasps.contiguous()
         B, M = grasps.shape[0], grasps.shape[1]
         dev = grasps.device
-        cm = torch.empty((B, M), dtype=torch.uint8, device=dev)
-        em = torch.empty((B, M), dtype=torch.uint8, device=dev) if return_empty_grasp else None
-        io = torch.empty((B, M, 5), dtype=torch.float32, device=dev) if return_ious else None
+        cm, em, io = _detect_outputs(B, M, dev, return_empty_grasp, return_ious)
         with torch.cuda.device(dev):
             L.check(L.lib().gn_collision_detect(self.scene_points.data_ptr(), None, self.scene_points.shape[0],
                                                 grasps.data_ptr(), L.ptr(counts), B, M, float(approach_dist),
                                                 float(collision_thresh), float(empty_thresh), float(self.voxel_size),
                                                 self.finger_width, self.finger_length, cm.data_ptr(), L.ptr(em), L.ptr(io),
                                                 _stream(grasps)), "collision_detect")
-        ret = [cm.bool()]
-        if return_empty_grasp:
-            ret.append(em.bool())
-        if return_ious:
-            ret.append(io)
-        return ret[0] if len(ret) == 1 else ret
+        return _detect_result(cm, em, io)
 
     def detect(self, grasp_group, approach_dist=0.03, collision_thresh=0.05, return_empty_grasp=False, empty_thresh=0.01,
                return_ious=False):
@@ -116,9 +179,23 @@ def sort_and_nms(grasps, counts=None, drop_mask=None, translation_thresh=0.03, r
     out = torch.empty_like(grasps)
     oc = torch.empty((B,), dtype=torch.int32, device=dev)
     ws = torch.empty((lib.gn_grasp_nms_workspace_bytes(B) if nms else 8,), dtype=torch.uint8, device=dev)
-    dm = None if drop_mask is None else drop_mask.to(torch.uint8).contiguous()
+    dm = None if drop_mask is None else (drop_mask.view(torch.uint8) if drop_mask.dtype == torch.bool else drop_mask.to(torch.uint8)).contiguous()
     with torch.cuda.device(dev):
         L.check(lib.gn_grasp_nms(grasps.data_ptr(), L.ptr(counts), L.ptr(dm), B, M, float(translation_thresh),
                                  float(rotation_thresh), 1 if nms else 0, ws.data_ptr(), out.data_ptr(), oc.data_ptr(),
                                  _stream(grasps)), "grasp_nms")
     return out, oc
+
+
+def grasp_pipeline(clouds, grasps, counts, voxel_size=0.01, approach_dist=0.05, collision_thresh=0.01,
+                   translation_thresh=0.03, rotation_thresh=30.0 / 180.0 * np.pi, nms=True, n_valid=None):
+    """What test.py:88-96 / demo_pointcloud.py:228-249 run on the host per scene after pred_decode -- voxel down-sample of the
+    scene, ModelFreeCollisionDetector.detect, drop the collisions, sort by score (+ NMS) -- for the whole batch on the device:
+    ~12 launches, no host read, no allocation besides torch's caching allocator, hipGraph-capturable.
+    clouds (B,N,3) f32, grasps (B,M,17) + counts (B,) as GraspNet.decode_padded() leaves them ->
+    (rows (B,M,17) sorted by score with zero padding, kept (B,) i32, collision mask (B,M) bool)."""
+    det = BatchedCollisionDetector(clouds, voxel_size, n_valid)
+    cm = det.detect_padded(grasps, counts, approach_dist=approach_dist, collision_thresh=collision_thresh)
+    out, oc = sort_and_nms(grasps, counts, drop_mask=cm, translation_thresh=translation_thresh,
+                           rotation_thresh=rotation_thresh, nms=nms)
+    return out, oc, cm

@@ -373,19 +373,40 @@ int gn_depth_to_cloud(const uint16_t *depth, int h, int w, double fx, double fy,
 
 /* open3d voxel_down_sample as used by utils/collision_detector.py:32-35 (un-vendored; restated:
  * origin = min_bound - voxel/2, voxel index = floor((p-origin)/voxel), output = mean of members in
- * float64; output order unspecified).  out (<=n,3) f64, out_count device int. */
+ * float64), for a whole batch of clouds in one call, no host read, DETERMINISTIC: the voxels of a cloud
+ * come out in order of first appearance (ascending lowest member index) and every mean adds its members
+ * in ascending index order, so two runs of one input are bit-identical (and equal to a sequential loop).
+ *   points (B,n,3) f32; n_valid (B) device ints (NULL = n everywhere): points past it are padding;
+ *   non-finite points belong to no voxel.
+ *   out (B,n,3) f64: rows [0, out_counts[b]) are the voxel means, the rest zero; out_counts (B);
+ *   status (B): 0 ok, 1 = the cloud spans more than 2^21 voxels on an axis, 2 = table overflow
+ *   (the offending points are left out). */
+size_t gn_voxel_batched_workspace_bytes(int b, int n);
+int gn_voxel_down_sample_batched(const float *points, const int32_t *n_valid, int b, int n, double voxel_size,
+                                 void *workspace /* 256-byte aligned */, double *out, int32_t *out_counts,
+                                 int32_t *status, gn_stream_t stream);
+/* one cloud: out (n,3) f64, out_count one device int; the first int of `workspace` is the status word. */
 size_t gn_voxel_workspace_bytes(int n);
 int gn_voxel_down_sample(const float *points, int n, double voxel_size, void *workspace, double *out,
                          int32_t *out_count, gn_stream_t stream);
 
 /* utils/collision_detector.py:69-129 ModelFreeCollisionDetector.detect for padded grasp lists:
- * scene_points (np,3) f64 (np read from np_dev if non-NULL), grasps (B,mpad,17) f32 rows as written
- * by gn_pred_decode, counts (B) valid rows (NULL = all mpad).  collision_mask / empty_mask (B,mpad) u8,
- * ious (B,mpad,5) f32 = [global,left,right,bottom,shifting]; empty_mask and ious may be NULL. */
+ * scene_points (np,3) f64 -- ONE scene for the whole batch, as the reference's detector object holds it
+ * (np_dev, if non-NULL, is one device int that bounds it: e.g. gn_voxel_down_sample's out_count) --
+ * grasps (B,mpad,17) f32 rows as written by gn_pred_decode, counts (B) valid rows (NULL = all mpad).
+ * collision_mask / empty_mask (B,mpad) u8, ious (B,mpad,5) f32 = [global,left,right,bottom,shifting];
+ * empty_mask and ious may be NULL. */
 int gn_collision_detect(const double *scene_points, const int32_t *np_dev, int np, const float *grasps,
                         const int32_t *counts, int b, int mpad, float approach_dist, double collision_thresh,
                         double empty_thresh, float voxel_size, float finger_width, float finger_length,
                         uint8_t *collision_mask, uint8_t *empty_mask, float *ious, gn_stream_t stream);
+/* the batch form of test.py:88-96 (one detector per scene there): scene b's points are rows
+ * [0, np_dev[b]) of scene_points (B,np_max,3) f64 -- exactly what gn_voxel_down_sample_batched leaves --
+ * np_dev (B) device ints (NULL = np_max everywhere).  One launch for the batch, no host read. */
+int gn_collision_detect_batched(const double *scene_points, int np_max, const int32_t *np_dev, const float *grasps,
+                                const int32_t *counts, int b, int mpad, float approach_dist, double collision_thresh,
+                                double empty_thresh, float voxel_size, float finger_width, float finger_length,
+                                uint8_t *collision_mask, uint8_t *empty_mask, float *ious, gn_stream_t stream);
 
 /* graspnetAPI GraspGroup.sort_by_score() and .nms() (grasp_nms.nms_grasp; un-vendored, parity unpinned):
  * rows with drop_mask != 0 (e.g. collisions; may be NULL) are removed, the rest sorted by score

@@ -42,6 +42,26 @@ SA_CFG = ((2048, 0.04, 64), (1024, 0.1, 32), (512, 0.2, 16), (256, 0.3, 16))  # 
 # parity runs.
 CALIBRATE_RNG = None
 
+# bench.py's cpu_baseline leg sets this to a dict to collect wall-clock seconds per stage (BASELINE.md section 4.3:
+# FPS, ball query, grouping, SA MLPs, FP, ApproachNet, cylinder query, CloudCrop MLP, heads, decode); None = no timing
+STAGE_TIMES = None
+
+
+class _stage:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if STAGE_TIMES is not None:
+            import time
+            self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        if STAGE_TIMES is not None:
+            import time
+            STAGE_TIMES[self.name] = STAGE_TIMES.get(self.name, 0.0) + time.perf_counter() - self.t0
+        return False
+
 
 def _bn(x, sd, p):
     if CALIBRATE_RNG is not None:
@@ -77,18 +97,23 @@ def _group(features, idx):
 
 def sa_module(xyz, features, sd, prefix, npoint, radius, nsample, dt=torch.float32):
     xyz_flipped = xyz.transpose(1, 2).contiguous()
-    inds = ops.furthest_point_sampling(xyz, npoint)
-    new_xyz = ops.gather_points(xyz_flipped, inds).transpose(1, 2).contiguous()
-    idx = ops.ball_query(new_xyz, xyz, radius, nsample)
-    grouped_xyz = ops.group_points(xyz_flipped, idx).to(dt)
-    grouped_xyz -= new_xyz.to(dt).transpose(1, 2).unsqueeze(-1)
-    grouped_xyz /= radius                      # normalize_xyz=True, backbone.py:36
-    if features is not None:
-        grouped = torch.cat([grouped_xyz, _group(features, idx)], dim=1)
-    else:
-        grouped = grouped_xyz
-    new_features = shared_mlp(grouped, sd, prefix + ".mlp_module", 3)
-    new_features = F.max_pool2d(new_features, kernel_size=[1, new_features.size(3)]).squeeze(-1)
+    with _stage("fps"):
+        inds = ops.furthest_point_sampling(xyz, npoint)
+    with _stage("grouping"):
+        new_xyz = ops.gather_points(xyz_flipped, inds).transpose(1, 2).contiguous()
+    with _stage("ball_query"):
+        idx = ops.ball_query(new_xyz, xyz, radius, nsample)
+    with _stage("grouping"):
+        grouped_xyz = ops.group_points(xyz_flipped, idx).to(dt)
+        grouped_xyz -= new_xyz.to(dt).transpose(1, 2).unsqueeze(-1)
+        grouped_xyz /= radius                      # normalize_xyz=True, backbone.py:36
+        if features is not None:
+            grouped = torch.cat([grouped_xyz, _group(features, idx)], dim=1)
+        else:
+            grouped = grouped_xyz
+    with _stage("sa_mlp"):
+        new_features = shared_mlp(grouped, sd, prefix + ".mlp_module", 3)
+        new_features = F.max_pool2d(new_features, kernel_size=[1, new_features.size(3)]).squeeze(-1)
     return new_xyz, new_features, inds
 
 
@@ -121,10 +146,12 @@ def backbone(pointcloud, sd, end_points, dt=torch.float32):
             end_points["sa%d_inds" % (li + 1)] = inds
         end_points["sa%d_xyz" % (li + 1)] = xyz
         end_points["sa%d_features" % (li + 1)] = features
-    f = fp_module(end_points["sa3_xyz"], end_points["sa4_xyz"], end_points["sa3_features"],
-                  end_points["sa4_features"], sd, p + ".fp1")
+    with _stage("fp"):
+        f = fp_module(end_points["sa3_xyz"], end_points["sa4_xyz"], end_points["sa3_features"],
+                      end_points["sa4_features"], sd, p + ".fp1")
     end_points["_fp1_features"] = f            # private (not a reference key): stage-level error attribution
-    f = fp_module(end_points["sa2_xyz"], end_points["sa3_xyz"], end_points["sa2_features"], f, sd, p + ".fp2")
+    with _stage("fp"):
+        f = fp_module(end_points["sa2_xyz"], end_points["sa3_xyz"], end_points["sa2_features"], f, sd, p + ".fp2")
     end_points["fp2_features"] = f
     end_points["fp2_xyz"] = end_points["sa2_xyz"]
     num_seed = end_points["fp2_xyz"].shape[1]
@@ -190,18 +217,21 @@ def cloud_crop(seed_xyz, pointcloud, vp_rot, sd, nsample=64, radius=0.05, hmin=-
     xyz_trans = pointcloud.transpose(1, 2).contiguous()
     grouped, idxs = [], []
     for hmax in hmax_list:
-        idx = ops.cylinder_query(seed_xyz, pointcloud, vp_rot.reshape(B, num_seed, 9).contiguous(),
-                                 radius, hmin, hmax, nsample)
+        with _stage("cylinder_query"):
+            idx = ops.cylinder_query(seed_xyz, pointcloud, vp_rot.reshape(B, num_seed, 9).contiguous(),
+                                     radius, hmin, hmax, nsample)
         idxs.append(idx)
-        g = ops.group_points(xyz_trans, idx).to(dt)
-        g -= seed_xyz.to(dt).transpose(1, 2).unsqueeze(-1)
-        g_ = g.permute(0, 2, 3, 1).contiguous()
-        g_ = torch.matmul(g_, vp_rot.to(dt))
-        grouped.append(g_.permute(0, 3, 1, 2).contiguous())
-    x = torch.stack(grouped, dim=3).view(B, -1, num_seed * len(hmax_list), nsample)
-    x = shared_mlp(x, sd, "grasp_generator.crop.mlps", 3)
-    x = F.max_pool2d(x, kernel_size=[1, x.size(3)])
-    x = x.view(B, -1, num_seed, len(hmax_list))
+        with _stage("grouping"):
+            g = ops.group_points(xyz_trans, idx).to(dt)
+            g -= seed_xyz.to(dt).transpose(1, 2).unsqueeze(-1)
+            g_ = g.permute(0, 2, 3, 1).contiguous()
+            g_ = torch.matmul(g_, vp_rot.to(dt))
+            grouped.append(g_.permute(0, 3, 1, 2).contiguous())
+    with _stage("crop_mlp"):
+        x = torch.stack(grouped, dim=3).view(B, -1, num_seed * len(hmax_list), nsample)
+        x = shared_mlp(x, sd, "grasp_generator.crop.mlps", 3)
+        x = F.max_pool2d(x, kernel_size=[1, x.size(3)])
+        x = x.view(B, -1, num_seed, len(hmax_list))
     if return_idx:
         return x, idxs
     return x
@@ -228,22 +258,29 @@ def forward(end_points, sd, num_view=300, num_angle=12, keep_internal=False, f64
         if f64:
             sd = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
         seed_features, seed_xyz, end_points = backbone(pc, sd, end_points, dt)
-        end_points = approach_net(seed_xyz, seed_features, sd, end_points, num_view, force_top_view_inds)
+        with _stage("approach_net"):
+            end_points = approach_net(seed_xyz, seed_features, sd, end_points, num_view, force_top_view_inds)
         vp, cyl_idx = cloud_crop(end_points["fp2_xyz"], end_points["input_xyz"],
                                  end_points["grasp_top_view_rot"], sd, return_idx=True, dt=dt)
         if keep_internal:
             end_points["_vp_features"] = vp
             end_points["_cylinder_idx"] = cyl_idx
-        op = head_net(vp, sd, "grasp_generator.operation")
-        end_points["grasp_score_pred"] = op[:, 0:num_angle]
-        end_points["grasp_angle_cls_pred"] = op[:, num_angle:2 * num_angle]
-        end_points["grasp_width_pred"] = op[:, 2 * num_angle:3 * num_angle]
-        end_points["grasp_tolerance_pred"] = head_net(vp, sd, "grasp_generator.tolerance")
+        with _stage("heads"):
+            op = head_net(vp, sd, "grasp_generator.operation")
+            end_points["grasp_score_pred"] = op[:, 0:num_angle]
+            end_points["grasp_angle_cls_pred"] = op[:, num_angle:2 * num_angle]
+            end_points["grasp_width_pred"] = op[:, 2 * num_angle:3 * num_angle]
+            end_points["grasp_tolerance_pred"] = head_net(vp, sd, "grasp_generator.tolerance")
     return end_points
 
 
 def pred_decode(end_points):
     """graspnet.py:77-134 -> list of (Ns_i,17) float32 rows."""
+    with _stage("decode"):
+        return _pred_decode(end_points)
+
+
+def _pred_decode(end_points):
     preds = []
     for i in range(len(end_points["point_clouds"])):
         objectness = end_points["objectness_score"][i].float()

@@ -33,6 +33,29 @@ def voxel_down_sample(points, voxel_size):
     return out / cnt[:, None]
 
 
+def voxel_down_sample_ordered(points, voxel_size, n_valid=None):
+    """The same voxel means with the output ORDER pinned (open3d leaves it unspecified): voxels in order of first appearance
+    (ascending lowest member index), each sum taken sequentially in ascending member index -- np.add.at is unbuffered and
+    walks the points in index order -- so a deterministic device implementation can be compared bit for bit.
+    Points past n_valid and non-finite points belong to no voxel."""
+    pts = np.asarray(points, dtype=np.float64)
+    if n_valid is not None:
+        pts = pts[:int(n_valid)]
+    pts = pts[np.isfinite(pts).all(axis=1)]
+    if len(pts) == 0:
+        return np.zeros((0, 3))
+    origin = pts.min(axis=0) - voxel_size * 0.5
+    vi = np.floor((pts - origin) / voxel_size).astype(np.int64)
+    _, first, inv, cnt = np.unique(vi, axis=0, return_index=True, return_inverse=True, return_counts=True)
+    inv = inv.reshape(-1)
+    order = np.argsort(first, kind="stable")            # sorted-voxel id of the k-th voxel to appear
+    rank = np.empty_like(order)
+    rank[order] = np.arange(len(order))
+    out = np.zeros((len(cnt), 3))
+    np.add.at(out, rank[inv], pts)
+    return out / cnt[order][:, None]
+
+
 def collision_detect(scene_points, grasps, approach_dist=0.03, collision_thresh=0.05, empty_thresh=0.01, voxel_size=0.005,
                      finger_width=0.01, finger_length=0.06):
     """scene_points (Np,3) float64, grasps (M,17) float32 -> collision mask, empty mask, [5 ious]."""

@@ -105,3 +105,54 @@ def test_bench_parent_exits_nonzero_when_a_rank_fails():
         pytest.skip("needs a box without a GPU")
     out = _bench(["--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0"])
     assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def _bench_module():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_sets_the_ipc_mode_for_both_launch_forms():
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC: RCCL needs it on this pool) is a setdefault at import time, so ranks that
+    arrive from an external torch.distributed.run get it too -- and a caller's explicit choice is kept"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import importlib.util, os; s = importlib.util.spec_from_file_location('b', 'bench.py'); m = importlib.util.module_from_spec(s); "
+            "s.loader.exec_module(m); print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY'], os.environ['GPU_MAX_HW_QUEUES'])")
+    for given, want in ((None, "0"), ("1", "1")):
+        env = {k: v for k, v in os.environ.items() if k not in ("HSA_ENABLE_IPC_MODE_LEGACY", "GPU_MAX_HW_QUEUES")}
+        if given is not None:
+            env["HSA_ENABLE_IPC_MODE_LEGACY"] = given
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0, out.stderr[-1500:]
+        assert out.stdout.split() == [want, "16"]
+
+
+def test_bench_rank_and_device_checks():
+    b = _bench_module()
+    # more local ranks than visible GPUs under RCCL: refused in words before init_process_group; gloo rehearsals may share
+    assert "only 1 visible GPU" in b.check_local_ranks(2, 2, 1, "nccl")
+    assert b.check_local_ranks(2, 2, 1, "gloo") is None and b.check_local_ranks(8, 8, 8, "nccl") is None
+    assert b.check_local_ranks(1, 1, 0, "nccl") is None
+    ok = [(r, r, r, "0000:%02x:00" % (5 + r)) for r in range(8)]
+    assert b.check_rank_devices(ok, 8, "nccl") is None
+    dup = ok[:7] + [(7, 7, 3, ok[3][3])]
+    msg = b.check_rank_devices(dup, 8, "nccl")
+    assert msg and "share device" in msg and ok[3][3] in msg and "7 -> cuda:3" in msg
+    assert b.check_rank_devices(dup, 8, "gloo") is None              # ranks sharing a card: a gloo rehearsal
+    assert "7 answered" in b.check_rank_devices(ok[:7], 8, "nccl")
+    assert "answered" in b.check_rank_devices(ok[:7] + [ok[0]], 8, "nccl")
+
+
+def test_bench_refuses_duplicate_devices_at_the_rendezvous():
+    """three ranks that all claim one device: with the RCCL rule applied the run stops with the rank -> device table and
+    prints no JSON line (GN_BENCH_FAKE_DEVICE / GN_BENCH_CHECK_AS stand in for GPUs on a CPU-only box)"""
+    out = _bench(["--gpus", "3", "--backend", "gloo", "--rendezvous-only"],
+                 {"GN_BENCH_FAKE_DEVICE": "0000:05:00", "GN_BENCH_CHECK_AS": "nccl"})
+    assert out.returncode != 0 and "share device" in out.stderr and "0000:05:00" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -469,7 +469,21 @@ def test_group_points_grad_on_a_real_padded_ball_query(E, oracle):
         torch.cuda.synchronize()
         times.append(a.elapsed_time(b))
         assert torch.equal(got2, got)
-    assert min(times) < 20.0, "group_points_grad on a padded ball_query index took %.1f ms" % min(times)
+    # "no ms-scale cliff" as a RATIO inside this run (not an absolute time: other processes may share the card): the same
+    # call on an index tensor without long segments is the yardstick
+    idx_flat = torch.randint(0, 20000, idx.shape, dtype=torch.int32, generator=torch.Generator().manual_seed(3))
+    idf = _dev(idx_flat)
+    E.group_points_grad(god, idf, 20000)
+    base = []
+    for _ in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        E.group_points_grad(god, idf, 20000)
+        b.record()
+        torch.cuda.synchronize()
+        base.append(a.elapsed_time(b))
+    assert min(times) < 60.0 * max(min(base), 0.05), \
+        "group_points_grad on a padded ball_query index took %.2f ms against %.2f ms without long segments" % (min(times), min(base))
 
 
 def test_knn_bit_exact(oracle):

@@ -48,6 +48,147 @@ def test_voxel_down_sample(scene):
     np.testing.assert_allclose(gs, ws, rtol=0, atol=1e-12)
 
 
+def _voxel_cases():
+    from graspnet_amd import synthetic as S
+    rng = np.random.default_rng(5)
+    n = 20000
+    uni = S.make_cloud(1000, n, "uniform")
+    sur = S.make_cloud(1001, n, "surface")                       # ~1000 duplicated points
+    one = np.tile(np.array([[0.1, -0.2, 0.5]], np.float32), (n, 1))     # ONE voxel of 20 000 members (> 4096: ballot rebuild)
+    one[::2] += np.float32(1e-4)
+    clumps = (rng.integers(0, 40, size=(n, 1)) * 0.02 + rng.uniform(0, 0.004, size=(n, 3))).astype(np.float32)   # ~500 per voxel
+    bad = sur.copy()
+    bad[[3, 77, 15000]] = [np.nan, np.inf, -np.inf]
+    zero = S.make_cloud(1002, n, "uniform")
+    zero[:, 0] -= zero[:, 0].mean()                              # coordinates straddling 0: tiny and large magnitudes together
+    clouds = np.stack([uni, sur, one, clumps, bad, zero])
+    n_valid = np.array([n, n, n, n, n, 12345], np.int32)
+    return clouds, n_valid
+
+
+@pytest.mark.parametrize("voxel", [0.005, 0.01])
+def test_voxel_down_sample_batched_bit_exact_and_deterministic(voxel):
+    """the batch form: no host read, output order = first appearance, sums in ascending member order -> equal BIT FOR BIT to
+    the sequential numpy restatement (oracle/post_oracle.voxel_down_sample_ordered) and to itself from run to run"""
+    from graspnet_amd import postprocess as P
+    from oracle import post_oracle as PO
+    clouds, n_valid = _voxel_cases()
+    pts = torch.from_numpy(clouds).cuda()
+    nv = torch.from_numpy(n_valid).cuda()
+    out, cnt, status = P.voxel_down_sample_batched(pts, voxel, n_valid=nv)
+    out2, cnt2, _ = P.voxel_down_sample_batched(pts, voxel, n_valid=nv)
+    assert torch.equal(out, out2) and torch.equal(cnt, cnt2)
+    assert not status.any()
+    o, c = out.cpu().numpy(), cnt.cpu().numpy()
+    for b in range(len(clouds)):
+        want = PO.voxel_down_sample_ordered(clouds[b], voxel, n_valid=n_valid[b])
+        assert c[b] == len(want), (b, c[b], len(want))
+        assert np.array_equal(o[b, :c[b]], want), b
+        assert not o[b, c[b]:].any()
+    # the one-cloud call is the same thing
+    one = P.voxel_down_sample(pts[1], voxel).cpu().numpy()
+    assert np.array_equal(one, o[1, :c[1]])
+
+
+def test_voxel_down_sample_reports_a_grid_beyond_2_21_cells():
+    from graspnet_amd import postprocess as P
+    pts = torch.tensor([[[0.0, 0.0, 0.0], [3.0e4, 0.0, 0.0], [0.001, 0.0, 0.0]]], device="cuda")
+    out, cnt, status = P.voxel_down_sample_batched(pts, 0.01)
+    assert status.cpu().tolist() == [1] and cnt.cpu().tolist() == [1]        # the far point is left out and reported
+    with pytest.raises(RuntimeError):
+        P.voxel_down_sample_batched(pts, 0.01, check=True)
+
+
+def test_collision_detect_batched_equals_one_detector_per_scene(state_dict):
+    """test.py:88-96 makes one detector per scene; the batch form must give every scene the verdicts of its own detector,
+    and those are the numpy restatement's (== the reference's detect(), tests/test_post_oracle.py)"""
+    from graspnet_amd import GraspNet, postprocess as P, synthetic as S
+    from oracle import post_oracle as PO
+    B = 4
+    clouds = torch.stack([torch.from_numpy(S.make_cloud(1001 + i, 20000, "surface")) for i in range(B)]).cuda()
+    net = GraspNet().load_state_dict(state_dict)
+    g, c = net.decode_padded(net({"point_clouds": clouds}))
+    det = P.BatchedCollisionDetector(clouds, voxel_size=0.01)
+    cm, em, io = det.detect_padded(g, c, approach_dist=0.05, collision_thresh=0.01, return_empty_grasp=True, return_ious=True)
+    cm2 = det.detect_padded(g, c, approach_dist=0.05, collision_thresh=0.01)
+    assert torch.equal(cm, cm2) and cm.dtype == torch.bool
+    counts = c.cpu().tolist()
+    nsc = det.scene_counts.cpu().tolist()
+    for b in range(B):
+        one = P.ModelFreeCollisionDetector(clouds[b], voxel_size=0.01)
+        assert one.scene_points.shape[0] == nsc[b]
+        assert torch.equal(one.scene_points, det.scene_points[b, :nsc[b]])
+        w = one.detect_padded(g[b:b + 1], c[b:b + 1], approach_dist=0.05, collision_thresh=0.01, return_empty_grasp=True,
+                              return_ious=True)
+        assert torch.equal(cm[b], w[0][0]) and torch.equal(em[b], w[1][0]) and torch.equal(io[b, :counts[b]], w[2][0, :counts[b]])
+        garr = g[b, :counts[b]].cpu().numpy()
+        wcm, wem, _ = PO.collision_detect(one.scene_points.cpu().numpy(), garr, approach_dist=0.05, collision_thresh=0.01,
+                                          voxel_size=0.01)
+        assert np.array_equal(cm[b, :counts[b]].cpu().numpy(), wcm) and np.array_equal(em[b, :counts[b]].cpu().numpy(), wem)
+        assert not cm[b, counts[b]:].any()
+    assert len({int(cm[b].sum()) for b in range(B)}) > 1          # the scenes really differ
+
+
+def test_collision_detect_batched_vs_reference_detect_golden(golden_dir):
+    """tests/golden/collision_ref.npz holds the outputs of the REFERENCE's ModelFreeCollisionDetector.detect
+    (utils/collision_detector.py:69-129, run by tests/golden/make_golden_collision.py in the build container) for three caller
+    settings; inputs are reproducible from seeds + the committed reference-python rows.  Device voxel down-sample + batched
+    detect: the same scene size, both masks bit for bit, the five IoUs equal after the float32 store."""
+    import importlib.util
+    import os
+    from graspnet_amd import postprocess as P
+    spec = importlib.util.spec_from_file_location("make_golden_collision", os.path.join(golden_dir, "make_golden_collision.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    cloud, rows = mg.inputs(golden_dir)
+    z = np.load(os.path.join(golden_dir, "collision_ref.npz"))
+    # the batch holds the scene twice: two different grasp subsets against their own copy of the scene
+    clouds = torch.from_numpy(np.stack([cloud, cloud])).cuda()
+    m = len(rows)
+    g = torch.zeros((2, m + 5, 17), device="cuda")
+    g[0, :m] = torch.from_numpy(rows).cuda()
+    g[1, :m - 9] = torch.from_numpy(rows[9:]).cuda()
+    c = torch.tensor([m, m - 9], dtype=torch.int32, device="cuda")
+    for ci in range(len(mg.CASES)):
+        ad, ct, et, vs = (float(v) for v in z["case%d/params" % ci])
+        det = P.BatchedCollisionDetector(clouds, voxel_size=vs)
+        assert det.scene_counts.cpu().tolist() == [int(z["case%d/n_scene" % ci][0])] * 2
+        cm, em, io = det.detect_padded(g, c, approach_dist=ad, collision_thresh=ct, return_empty_grasp=True, empty_thresh=et,
+                                       return_ious=True)
+        cm, em, io = cm.cpu().numpy(), em.cpu().numpy(), io.cpu().numpy()
+        wcm, wem = z["case%d/collision_mask" % ci], z["case%d/empty_mask" % ci]
+        assert np.array_equal(cm[0, :m], wcm) and np.array_equal(cm[1, :m - 9], wcm[9:])
+        assert np.array_equal(em[0, :m], wem) and np.array_equal(em[1, :m - 9], wem[9:])
+        assert not cm[:, m:].any()
+        with np.errstate(all="ignore"):
+            for k, name in enumerate(("global", "left", "right", "bottom", "shifting")):
+                want = z["case%d/iou_%s" % (ci, name)].astype(np.float32)
+                assert np.array_equal(io[0, :m, k], want, equal_nan=True), (ci, name)
+                assert np.array_equal(io[1, :m - 9, k], want[9:], equal_nan=True), (ci, name)
+
+
+def test_full_pipeline_is_graph_capturable_and_sync_free(state_dict):
+    """forward -> pred_decode -> voxel down-sample -> collision filter -> sort + NMS captured as ONE hipGraph (nothing in the
+    C ABI reads back or allocates): a replay equals the eager result, and two replays equal each other bit for bit"""
+    from graspnet_amd import GraspNet, GraphedGraspNet, postprocess as P, synthetic as S
+    clouds = S.make_batch(1000, 4, 20000, "surface").cuda()
+    net = GraspNet().load_state_dict(state_dict)
+    g, c = net.decode_padded(net({"point_clouds": clouds}))
+    want_rows, want_kept, want_cm = P.grasp_pipeline(clouds, g, c)
+    torch.cuda.synchronize()
+    gnet = GraphedGraspNet(net, batch=4, points=20000, post=dict(voxel_size=0.01, approach_dist=0.05, collision_thresh=0.01))
+    _, _, _, rows, kept, cm = gnet(clouds)
+    torch.cuda.synchronize()
+    assert torch.equal(kept, want_kept) and torch.equal(cm, want_cm) and torch.equal(rows, want_rows)
+    r1, k1 = rows.clone(), kept.clone()
+    gnet(S.make_batch(2000, 4, 20000, "uniform").cuda())
+    _, _, _, rows, kept, cm = gnet(clouds)
+    torch.cuda.synchronize()
+    assert torch.equal(rows, r1) and torch.equal(kept, k1)
+    k = kept.cpu().tolist()
+    assert all(0 < k[b] < int(c[b]) for b in range(4))
+
+
 def test_collision_detector_matches_reference_formula(scene, grasps):
     from graspnet_amd import postprocess as P
     from oracle import post_oracle as PO

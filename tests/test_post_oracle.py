@@ -19,6 +19,32 @@ def test_voxel_down_sample_means():
     assert any(np.allclose(r, [0.0005, 0.0005, 0.0005], atol=1e-9) for r in v)
 
 
+def test_voxel_down_sample_ordered_is_the_same_set_in_first_appearance_order():
+    from oracle import post_oracle as PO
+    from graspnet_amd import synthetic as S
+    cloud = S.make_cloud(1001, 6000, "surface")
+    a = PO.voxel_down_sample(cloud, 0.01)
+    b = PO.voxel_down_sample_ordered(cloud, 0.01)
+    assert a.shape == b.shape
+    assert np.array_equal(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])        # same means, bit for bit
+    # first voxel to appear holds point 0; order = ascending lowest member index
+    origin = cloud.astype(np.float64).min(axis=0) - 0.005
+    vi = np.floor((cloud.astype(np.float64) - origin) / 0.01).astype(np.int64)
+    seen, firsts = set(), []
+    for i, v in enumerate(map(tuple, vi)):
+        if v not in seen:
+            seen.add(v)
+            firsts.append(i)
+    assert len(firsts) == len(b)
+    vb = np.floor((b - origin) / 0.01).astype(np.int64)
+    assert np.array_equal(vb, vi[firsts])
+    # padding and non-finite points belong to no voxel
+    c2 = cloud.copy()
+    c2[7] = np.nan
+    assert np.array_equal(PO.voxel_down_sample_ordered(c2, 0.01, n_valid=3000),
+                          PO.voxel_down_sample_ordered(np.delete(cloud[:3000], 7, axis=0), 0.01))
+
+
 def test_collision_box_counts():
     from oracle import post_oracle as PO
     g = np.zeros((1, 17), np.float32)

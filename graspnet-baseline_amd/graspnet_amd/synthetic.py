@@ -93,13 +93,22 @@ def _shared_mlp(sd, rng, prefix, spec):
                  spec[i + 1], spec[i], 2, bias=False)
 
 
-def make_state_dict(seed=0, calibrated=True, num_view=NUM_VIEW):
+def make_state_dict(seed=0, calibrated=True, num_view=NUM_VIEW, variant=None):
     """Seeded, perturbed weights (random BN statistics/affine, non-zero biases):
     default-initialised BN makes every seed pick the same view.
     With calibrated=True and data/bn_calib_s<seed>.npz present (written by
     tests/golden/calibrate_bn.py), the BN running statistics are replaced by
     calibrated ones so the random network behaves like a trained one (diverse
-    approach views, non-trivial objectness mask)."""
+    approach views, non-trivial objectness mask).
+
+    variant (parity fixtures, tests/golden/make_golden.py):
+      "unit": the two heads' last layers rescaled by powers of two (score rows x 1/4, tolerance x 1/128) so that the
+              raw scores stay within ~[-1.2, 1.2], the tolerances within ~0.05 = GRASP_MAX_TOLERANCE (what training
+              drives them to, loss_utils.py:9) and the decoded score*tolerance/0.05 (models/graspnet.py:121) is O(1)
+              -- the regime in which "within 1e-4 on grasp scores" is a plain absolute statement;
+      "tied": exact arg-max ties by construction -- the view rows of ApproachNet's last layer are equal in triples
+              (views 3k, 3k+1, 3k+2) and the angle-class rows of OperationNet's last layer in pairs (2k, 2k+1), so
+              torch.max / torch.argmax (modules.py:64, graspnet.py:93) decide by their first-maximum rule on every seed."""
     rng = np.random.default_rng(seed)
     sd = {}
     bb = "view_estimator.backbone"
@@ -127,4 +136,23 @@ def make_state_dict(seed=0, calibrated=True, num_view=NUM_VIEW):
                         continue            # the calibration file is for 300 views: layers sized by num_view keep their seeds
                     assert k in sd and tuple(sd[k].shape) == z[k].shape, k
                     sd[k] = torch.from_numpy(z[k].copy())
+    if variant == "unit":
+        op, tol = "grasp_generator.operation.conv3", "grasp_generator.tolerance.conv3"
+        for k in (".weight", ".bias"):
+            sd[op + k] = sd[op + k].clone()
+            sd[op + k][0:NUM_ANGLE] *= 0.25
+            sd[tol + k] = sd[tol + k] * (1.0 / 128.0)
+    elif variant == "tied":
+        vp3, op3 = "view_estimator.vpmodule.conv3", "grasp_generator.operation.conv3"
+        for k in (".weight", ".bias"):
+            t = sd[vp3 + k].clone()
+            for v in range(num_view):
+                t[2 + v] = t[2 + (v // 3) * 3]
+            sd[vp3 + k] = t
+            t = sd[op3 + k].clone()
+            for a in range(NUM_ANGLE):
+                t[NUM_ANGLE + a] = t[NUM_ANGLE + (a // 2) * 2]
+            sd[op3 + k] = t
+    elif variant is not None:
+        raise ValueError("unknown weight variant %r" % (variant,))
     return sd

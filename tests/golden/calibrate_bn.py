@@ -39,4 +39,5 @@ def main(seed=0):
 
 
 if __name__ == "__main__":
-    main()
+    for sd_seed in ([int(a) for a in sys.argv[1:]] or [0]):
+        main(sd_seed)

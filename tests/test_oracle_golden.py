@@ -109,3 +109,31 @@ def test_example_scene_fixture(model_oracle, state_dict, golden_dir):
     assert len(scene) == int(z["n_scene_voxels"][0])
     cm, _, _ = PO.collision_detect(scene, z["grasps"], approach_dist=0.05, collision_thresh=0.01, voxel_size=0.01)
     assert np.array_equal(cm, z["collision_mask"])
+
+
+@pytest.mark.parametrize("case", ["s1", "unit", "tied"])
+def test_model_oracle_reproduces_the_variant_goldens(model_oracle, golden_dir, case):
+    """tests/golden/model_<case>_n20000.npz (reference python run by make_golden_variants.py): more weight seeds, O(1)-score
+    weights, exact arg-max ties.  The oracle on the same seeds: indices and the discrete choices exact, floats within 1e-4."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("make_golden_variants", os.path.join(golden_dir, "make_golden_variants.py"))
+    mv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mv)
+    g = np.load(os.path.join(golden_dir, "model_%s_n20000.npz" % case))
+    sd, cl = mv.state_dict_of(case), mv.cloud_of(case)
+    ep = model_oracle.forward({"point_clouds": cl}, sd)
+    p = model_oracle.pred_decode(ep)[0].numpy()
+    for k in ("sa1_inds", "sa2_inds", "grasp_top_view_inds"):
+        assert np.array_equal(ep[k].numpy(), g["model/" + k]), k
+    for k in ("view_score", "grasp_score_pred", "grasp_tolerance_pred"):
+        np.testing.assert_allclose(ep[k].contiguous().reshape(-1)[::97].numpy(), g["model/%s/sample" % k], rtol=1e-4, atol=1e-4)
+    assert p.shape == g["model/pred/0"].shape
+    np.testing.assert_allclose(p, g["model/pred/0"], rtol=1e-4, atol=1e-4)
+    if case == "unit":
+        assert float(np.abs(p[:, 0]).max()) < 2.0
+        np.testing.assert_allclose(p[:, 0], g["model/pred/0"][:, 0], rtol=0, atol=1e-4)      # plain absolute 1e-4 on scores
+    if case == "tied":
+        vs = ep["view_score"][0]
+        assert torch.equal(vs[:, 0::3], vs[:, 1::3]) and bool((ep["grasp_top_view_inds"] % 3 == 0).all())
+        assert int(g["tied/depth_score_ties"][0]) > 10

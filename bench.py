@@ -625,6 +625,49 @@ def main():
         extra["full_pipeline"] = fp
         log("full-pipeline leg done: %.3f ms/step on %d streams" % (fp["ms_per_step"], len(streams)))
 
+    if world == 1 and "dropin" in legs:
+        # drop-in MODE: the reference's unfused python composition (tests/dropin_harness.py -- ~30 `_ext` calls per forward in
+        # the reference's order, torch-on-GPU layers between them) over graspnet_amd.pointnet2_ext + graspnet_amd.pred_decode:
+        # the figure a maintainer gets from replacing only pointnet2/_ext (pointnet2_utils.py:26).  Harness code, product
+        # operators; one stream, like the reference's own loop (test.py:82-96).
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import dropin_harness as DH
+            from graspnet_amd import pointnet2_ext as DE, pred_decode as gn_pred_decode
+            sdd = DH.to_device(sd, dev)
+
+            def dropin_step(x):
+                with torch.no_grad():
+                    ep_d = DH.forward(DE, x, sdd)
+                return net.decode_padded(ep_d)
+
+            def dropin_time(n):
+                dropin_step(sets[0])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(n):
+                    dropin_step(sets[i % NSETS])
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n
+
+            kd = max(5, min(args.steps, 20))
+            td = dropin_time(kd)
+            os.environ["GN_GRID_CACHE"] = "0"
+            td0 = dropin_time(kd)
+            os.environ["GN_GRID_CACHE"] = "1"
+            DE.clear_grid_cache()
+            extra["dropin_unfused_scenes_per_s"] = B / td
+            extra["dropin_unfused"] = {"scenes_per_s": B / td, "ms_per_forward": td * 1e3, "steps": kd,
+                                       "ms_per_forward_without_grid_reuse": td0 * 1e3,
+                                       "fraction_of_single_stream_fused": (B / td) / extra.get("single_stream_scenes_per_s", float("nan")),
+                                       "note": "unfused reference composition (harness) on torch-GPU layers over the drop-in "
+                                               "operators; one stream; the fused path is `single_stream_scenes_per_s`"}
+            del sdd
+            torch.cuda.empty_cache()
+            log("drop-in unfused leg done: %.2f ms per forward" % (td * 1e3))
+        except Exception as ex:          # a leg beside the headline never takes the line down
+            extra["dropin_unfused"] = None
+            extra["dropin_unfused_error"] = str(ex)[:300]
     if rank == 0:
         # dominance by CU-time: FPS is the longest kernel but runs on B of the 256 CUs
         cu_share = {k: (B / 256.0 if k.startswith("furthest_point_sampling") else 1.0) for k in stages}

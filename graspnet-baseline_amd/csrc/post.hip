@@ -253,35 +253,32 @@ static VoxelWs voxel_carve(void *base, int b, int n) {
 // collision detection: one workgroup per grasp, float64 like numpy on open3d's float64 points
 // ------------------------------------------------------------------------------------------------
 struct CollisionParams {
-  float finger_width, finger_length, voxel_size;
+  double voxel_size;            // a python float in the reference: voxel_size ** 3 is taken in double, then meets float32 arrays
+  float finger_width, finger_length;
   float approach_dist;          // already max(approach_dist, finger_width)  (collision_detector.py:69)
   double collision_thresh, empty_thresh;
 };
 
-__global__ __launch_bounds__(256) void collision_kernel(const double *__restrict__ scene, size_t scene_stride,
-                                                        const int *__restrict__ np_ptr, int np_stride,
-                                                        int np_fixed, const float *__restrict__ grasps, int ldg,
-                                                        const int32_t *__restrict__ counts, int mpad,
-                                                        CollisionParams P, uint8_t *__restrict__ collision_mask,
-                                                        uint8_t *__restrict__ empty_mask, float *__restrict__ ious) {
-  __shared__ int s_cnt[6];
-  const int g = blockIdx.x;             // grasp row within the scene's padded list
-  const int b = blockIdx.y;
-  const int m_valid = counts ? counts[b] : mpad;
-  const size_t orow = (size_t)b * mpad + g;
-  if (g >= m_valid) {                   // padding row
-    if (threadIdx.x == 0) {
-      collision_mask[orow] = 0;
-      if (empty_mask) empty_mask[orow] = 0;
-    }
-    return;
-  }
-  if (threadIdx.x < 6) s_cnt[threadIdx.x] = 0;
-  __syncthreads();
-  // scene b's own down-sampled cloud (scene_stride doubles apart; 0 = one scene for the whole batch) and point count
-  scene += (size_t)b * scene_stride;
-  const int np = np_ptr ? min(np_ptr[(size_t)b * np_stride], np_fixed) : np_fixed;
-  const float *gr = grasps + orow * ldg;
+// One workgroup = COL_GB grasps of one scene against ALL of the scene's points.
+//   * the counts the reference takes are tiny (a gripper's boxes hold ~5-50 of a scene's ~10^4 voxel points), so every
+//     (point, grasp) pair first meets a CONSERVATIVE float32 test against the union of the boxes in the grasp frame, widened
+//     by eps (the float32 evaluation's error bound for a point that truly lies inside: its |p| <= |T| + the box extent, so
+//     |t_f32 - t| <= ~(|T|_1 + 1) * 2^-22; eps is 4x that); only pairs that pass are evaluated in float64 exactly as numpy
+//     does (collision_detector.py:80-129) and bump the grasp's six LDS counters.  A pair that fails is outside every box in
+//     exact arithmetic too, so the counts -- integers -- are the reference's;
+//   * a thread keeps COL_K points in registers per tile and walks the workgroup's grasps over them (per-grasp constants
+//     from LDS, broadcast), so the scene is read once per workgroup instead of once per grasp (the round-3 kernel moved
+//     2.2 GB through L2 per batch and did the float64 transform for every pair).
+constexpr int COL_GB = 8, COL_K = 4;
+
+struct ColGrasp {            // float32 pre-test constants of one grasp, 16 floats
+  float r[9];                // R row-major: targets = (p - T) @ R
+  float t[3];
+  float xlo, xhi, yb, zb;    // union of the four boxes + the inner box, widened by eps
+};
+
+__device__ __forceinline__ void collision_exact(const double *__restrict__ sp, const float *__restrict__ gr,
+                                                const CollisionParams &P, int *cnt) {
   const float width = gr[1], height = gr[2], depth = gr[3];
   double R[9], T[3];
   for (int i = 0; i < 9; ++i) R[i] = (double)gr[4 + i];
@@ -296,49 +293,115 @@ __global__ __launch_bounds__(256) void collision_kernel(const double *__restrict
   const double y6 = (double)(width / 2.0f);
   const double x_b = (double)(depth - P.finger_length - P.finger_width);
   const double x_s = (double)(depth - P.finger_length - P.finger_width - P.approach_dist);
-  int c_left = 0, c_right = 0, c_bottom = 0, c_shift = 0, c_global = 0, c_inner = 0;
-  for (int i = threadIdx.x; i < np; i += 256) {
-    const double dx = scene[i * 3 + 0] - T[0], dy = scene[i * 3 + 1] - T[1], dz = scene[i * 3 + 2] - T[2];
-    // targets = (scene - T) @ R  (:80-81)
-    const double tx = dx * R[0] + dy * R[3] + dz * R[6];
-    const double ty = dx * R[1] + dy * R[4] + dz * R[7];
-    const double tz = dx * R[2] + dy * R[5] + dz * R[8];
-    const bool m1 = tz > zlo && tz < zhi;
-    const bool m2 = tx > x_fl && tx < x_d;
-    const bool m3 = ty > y3, m4 = ty < y4, m5 = ty < y5, m6 = ty > y6;
-    const bool m7 = tx <= x_fl && tx > x_b;
-    const bool m8 = tx <= x_b && tx > x_s;
-    const bool left = m1 && m2 && m3 && m4;
-    const bool right = m1 && m2 && m5 && m6;
-    const bool bottom = m1 && m3 && m5 && m7;
-    const bool shift = m1 && m3 && m5 && m8;
-    c_left += left; c_right += right; c_bottom += bottom; c_shift += shift;
-    c_global += (left || right || bottom || shift);
-    c_inner += (m1 && m2 && !m4 && !m6);
+  const double dx = sp[0] - T[0], dy = sp[1] - T[1], dz = sp[2] - T[2];
+  // targets = (scene - T) @ R  (:80-81)
+  const double tx = dx * R[0] + dy * R[3] + dz * R[6];
+  const double ty = dx * R[1] + dy * R[4] + dz * R[7];
+  const double tz = dx * R[2] + dy * R[5] + dz * R[8];
+  const bool m1 = tz > zlo && tz < zhi;
+  const bool m2 = tx > x_fl && tx < x_d;
+  const bool m3 = ty > y3, m4 = ty < y4, m5 = ty < y5, m6 = ty > y6;
+  const bool m7 = tx <= x_fl && tx > x_b;
+  const bool m8 = tx <= x_b && tx > x_s;
+  const bool left = m1 && m2 && m3 && m4;
+  const bool right = m1 && m2 && m5 && m6;
+  const bool bottom = m1 && m3 && m5 && m7;
+  const bool shift = m1 && m3 && m5 && m8;
+  if (left || right || bottom || shift) atomicAdd(&cnt[0], 1);
+  if (left) atomicAdd(&cnt[1], 1);
+  if (right) atomicAdd(&cnt[2], 1);
+  if (bottom) atomicAdd(&cnt[3], 1);
+  if (shift) atomicAdd(&cnt[4], 1);
+  if (m1 && m2 && !m4 && !m6) atomicAdd(&cnt[5], 1);
+}
+
+__global__ __launch_bounds__(256) void collision_kernel(const double *__restrict__ scene, size_t scene_stride,
+                                                        const int *__restrict__ np_ptr, int np_stride,
+                                                        int np_fixed, const float *__restrict__ grasps, int ldg,
+                                                        const int32_t *__restrict__ counts, int mpad,
+                                                        CollisionParams P, uint8_t *__restrict__ collision_mask,
+                                                        uint8_t *__restrict__ empty_mask, float *__restrict__ ious) {
+  __shared__ int s_cnt[COL_GB][8];
+  __shared__ ColGrasp s_g[COL_GB];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int g0 = blockIdx.x * COL_GB;
+  const int m_valid = counts ? min(counts[b], mpad) : mpad;
+  const int ng = min(COL_GB, m_valid - g0);          // grasps of this workgroup that exist; the rest are padding rows
+  if (tid < COL_GB && g0 + tid < mpad && tid >= max(ng, 0)) {
+    const size_t orow = (size_t)b * mpad + g0 + tid;
+    collision_mask[orow] = 0;
+    if (empty_mask) empty_mask[orow] = 0;
+    if (ious) for (int k = 0; k < 5; ++k) ious[orow * 5 + k] = 0.f;
   }
-  atomicAdd(&s_cnt[0], c_global); atomicAdd(&s_cnt[1], c_left); atomicAdd(&s_cnt[2], c_right);
-  atomicAdd(&s_cnt[3], c_bottom); atomicAdd(&s_cnt[4], c_shift); atomicAdd(&s_cnt[5], c_inner);
+  if (ng <= 0) return;
+  // scene b's own down-sampled cloud (scene_stride doubles apart; 0 = one scene for the whole batch) and point count
+  scene += (size_t)b * scene_stride;
+  const int np = np_ptr ? min(np_ptr[(size_t)b * np_stride], np_fixed) : np_fixed;
+  const float *grow = grasps + ((size_t)b * mpad + g0) * ldg;
+  if (tid < COL_GB * 8) s_cnt[tid >> 3][tid & 7] = 0;
+  if (tid < ng) {
+    const float *gr = grow + (size_t)tid * ldg;
+    ColGrasp c;
+    for (int i = 0; i < 9; ++i) c.r[i] = gr[4 + i];
+    for (int i = 0; i < 3; ++i) c.t[i] = gr[13 + i];
+    const float width = gr[1], height = gr[2], depth = gr[3];
+    const float eps = 2e-6f * (fabsf(c.t[0]) + fabsf(c.t[1]) + fabsf(c.t[2]) + 1.0f);
+    c.xlo = depth - P.finger_length - P.finger_width - P.approach_dist - eps;
+    c.xhi = depth + eps;
+    c.yb = fabsf(width) * 0.5f + P.finger_width + eps;
+    c.zb = fabsf(height) * 0.5f + eps;
+    s_g[tid] = c;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const float vs3 = (float)((double)P.voxel_size * (double)P.voxel_size * (double)P.voxel_size);  // python float **3
+  for (int base = 0; base < np; base += 256 * COL_K) {
+    float px[COL_K], py[COL_K], pz[COL_K];
+#pragma unroll
+    for (int k = 0; k < COL_K; ++k) {
+      const int i = base + k * 256 + tid;
+      if (i < np) {
+        px[k] = (float)scene[(size_t)i * 3]; py[k] = (float)scene[(size_t)i * 3 + 1]; pz[k] = (float)scene[(size_t)i * 3 + 2];
+      } else {
+        px[k] = py[k] = pz[k] = INFINITY;       // fails every test (Inf - T = Inf, Inf * 0 = NaN: all compares false)
+      }
+    }
+    for (int g = 0; g < ng; ++g) {
+      const ColGrasp c = s_g[g];
+#pragma unroll
+      for (int k = 0; k < COL_K; ++k) {
+        const float dx = px[k] - c.t[0], dy = py[k] - c.t[1], dz = pz[k] - c.t[2];
+        const float tx = fmaf(dz, c.r[6], fmaf(dy, c.r[3], dx * c.r[0]));
+        const float ty = fmaf(dz, c.r[7], fmaf(dy, c.r[4], dx * c.r[1]));
+        const float tz = fmaf(dz, c.r[8], fmaf(dy, c.r[5], dx * c.r[2]));
+        if (fabsf(tz) < c.zb && fabsf(ty) < c.yb && tx > c.xlo && tx < c.xhi)
+          collision_exact(scene + (size_t)(base + k * 256 + tid) * 3, grow + (size_t)g * ldg, P, s_cnt[g]);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < ng) {
+    const float *gr = grow + (size_t)tid * ldg;
+    const float width = gr[1], height = gr[2];
+    const int *cnt = s_cnt[tid];
+    const size_t orow = (size_t)b * mpad + g0 + tid;
+    const float vs3 = (float)(P.voxel_size * P.voxel_size * P.voxel_size);  // python float ** 3, then float32 / python float
     // float32 volume expressions, evaluated left to right (:113-116)
     const float lr_vol = height * P.finger_length * P.finger_width / vs3;
     const float bottom_vol = height * (width + 2.0f * P.finger_width) * P.finger_width / vs3;
     const float shift_vol = height * (width + 2.0f * P.finger_width) * P.approach_dist / vs3;
     const float volume = lr_vol * 2.0f + bottom_vol + shift_vol;
-    const double giou = (double)s_cnt[0] / (double)(volume + 1e-6f);     // int64 / float32 -> float64 (:119)
+    const double giou = (double)cnt[0] / (double)(volume + 1e-6f);     // int64 / float32 -> float64 (:119)
     collision_mask[orow] = giou > P.collision_thresh;
     if (empty_mask) {
       const float inner_vol = height * P.finger_length * width / vs3;
-      empty_mask[orow] = ((double)s_cnt[5] / (double)inner_vol) < P.empty_thresh;
+      empty_mask[orow] = ((double)cnt[5] / (double)inner_vol) < P.empty_thresh;
     }
     if (ious) {
       float *o = ious + orow * 5;
       o[0] = (float)giou;
-      o[1] = (float)((double)s_cnt[1] / (double)(lr_vol + 1e-6f));
-      o[2] = (float)((double)s_cnt[2] / (double)(lr_vol + 1e-6f));
-      o[3] = (float)((double)s_cnt[3] / (double)(bottom_vol + 1e-6f));
-      o[4] = (float)((double)s_cnt[4] / (double)(shift_vol + 1e-6f));
+      o[1] = (float)((double)cnt[1] / (double)(lr_vol + 1e-6f));
+      o[2] = (float)((double)cnt[2] / (double)(lr_vol + 1e-6f));
+      o[3] = (float)((double)cnt[3] / (double)(bottom_vol + 1e-6f));
+      o[4] = (float)((double)cnt[4] / (double)(shift_vol + 1e-6f));
     }
   }
 }
@@ -533,7 +596,7 @@ extern "C" int gn_voxel_down_sample(const float *points, int n, double voxel_siz
 
 static int collision_launch(const double *scene_points, size_t scene_stride, const int32_t *np_dev, int np_stride, int np,
                             const float *grasps, const int32_t *counts, int b, int mpad, float approach_dist,
-                            double collision_thresh, double empty_thresh, float voxel_size, float finger_width,
+                            double collision_thresh, double empty_thresh, double voxel_size, float finger_width,
                             float finger_length, uint8_t *collision_mask, uint8_t *empty_mask, float *ious,
                             gn_stream_t stream) {
   GN_REQUIRE(b >= 0 && mpad >= 0 && np >= 0, "collision_detect: bad sizes");
@@ -547,7 +610,7 @@ static int collision_launch(const double *scene_points, size_t scene_stride, con
   P.approach_dist = approach_dist > finger_width ? approach_dist : finger_width;   // collision_detector.py:69
   P.collision_thresh = collision_thresh;
   P.empty_thresh = empty_thresh;
-  hipLaunchKernelGGL(collision_kernel, dim3(mpad, b), dim3(256), 0, as_stream(stream), scene_points, scene_stride, np_dev,
+  hipLaunchKernelGGL(collision_kernel, dim3((mpad + COL_GB - 1) / COL_GB, b), dim3(256), 0, as_stream(stream), scene_points, scene_stride, np_dev,
                      np_stride, np, grasps, 17, counts, mpad, P, collision_mask, empty_mask, ious);
   GN_CHECK_LAUNCH("collision_detect");
   return GN_OK;
@@ -555,7 +618,7 @@ static int collision_launch(const double *scene_points, size_t scene_stride, con
 
 extern "C" int gn_collision_detect(const double *scene_points, const int32_t *np_dev, int np, const float *grasps,
                                    const int32_t *counts, int b, int mpad, float approach_dist, double collision_thresh,
-                                   double empty_thresh, float voxel_size, float finger_width, float finger_length,
+                                   double empty_thresh, double voxel_size, float finger_width, float finger_length,
                                    uint8_t *collision_mask, uint8_t *empty_mask, float *ious, gn_stream_t stream) {
   // np_dev (one device int, e.g. gn_voxel_down_sample's out_count) bounds the scene when given; np is then its capacity
   GN_REQUIRE(np_dev || np >= 0, "collision_detect: bad sizes");
@@ -566,7 +629,7 @@ extern "C" int gn_collision_detect(const double *scene_points, const int32_t *np
 
 extern "C" int gn_collision_detect_batched(const double *scene_points, int np_max, const int32_t *np_dev, const float *grasps,
                                            const int32_t *counts, int b, int mpad, float approach_dist,
-                                           double collision_thresh, double empty_thresh, float voxel_size, float finger_width,
+                                           double collision_thresh, double empty_thresh, double voxel_size, float finger_width,
                                            float finger_length, uint8_t *collision_mask, uint8_t *empty_mask, float *ious,
                                            gn_stream_t stream) {
   return collision_launch(scene_points, (size_t)(np_max > 0 ? np_max : 0) * 3, np_dev, 1, np_max, grasps, counts, b, mpad,

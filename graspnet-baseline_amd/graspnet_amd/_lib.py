@@ -122,12 +122,12 @@ SIGNATURES = {
     "gn_voxel_down_sample_batched": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, ctypes.c_double, _c_void_p, _c_void_p,
                                              _c_void_p, _c_void_p, _c_void_p]),
     "gn_collision_detect_batched": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_float,
-                                             ctypes.c_double, ctypes.c_double, _c_float, _c_float, _c_float, _c_void_p,
+                                             ctypes.c_double, ctypes.c_double, ctypes.c_double, _c_float, _c_float, _c_void_p,
                                              _c_void_p, _c_void_p, _c_void_p]),
     "gn_voxel_workspace_bytes": (_c_size_t, [_c_int]),
     "gn_voxel_down_sample": (_c_int, [_c_void_p, _c_int, ctypes.c_double, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "gn_collision_detect": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_float,
-                                     ctypes.c_double, ctypes.c_double, _c_float, _c_float, _c_float, _c_void_p, _c_void_p,
+                                     ctypes.c_double, ctypes.c_double, ctypes.c_double, _c_float, _c_float, _c_void_p, _c_void_p,
                                      _c_void_p, _c_void_p]),
     "gn_grasp_nms_workspace_bytes": (_c_size_t, [_c_int]),
     "gn_grasp_nms": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, ctypes.c_double, ctypes.c_double, _c_int,

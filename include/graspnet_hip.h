@@ -398,14 +398,14 @@ int gn_voxel_down_sample(const float *points, int n, double voxel_size, void *wo
  * empty_mask and ious may be NULL. */
 int gn_collision_detect(const double *scene_points, const int32_t *np_dev, int np, const float *grasps,
                         const int32_t *counts, int b, int mpad, float approach_dist, double collision_thresh,
-                        double empty_thresh, float voxel_size, float finger_width, float finger_length,
+                        double empty_thresh, double voxel_size, float finger_width, float finger_length,
                         uint8_t *collision_mask, uint8_t *empty_mask, float *ious, gn_stream_t stream);
 /* the batch form of test.py:88-96 (one detector per scene there): scene b's points are rows
  * [0, np_dev[b]) of scene_points (B,np_max,3) f64 -- exactly what gn_voxel_down_sample_batched leaves --
  * np_dev (B) device ints (NULL = np_max everywhere).  One launch for the batch, no host read. */
 int gn_collision_detect_batched(const double *scene_points, int np_max, const int32_t *np_dev, const float *grasps,
                                 const int32_t *counts, int b, int mpad, float approach_dist, double collision_thresh,
-                                double empty_thresh, float voxel_size, float finger_width, float finger_length,
+                                double empty_thresh, double voxel_size, float finger_width, float finger_length,
                                 uint8_t *collision_mask, uint8_t *empty_mask, float *ious, gn_stream_t stream);
 
 /* graspnetAPI GraspGroup.sort_by_score() and .nms() (grasp_nms.nms_grasp; un-vendored, parity unpinned):

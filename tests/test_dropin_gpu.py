@@ -1,0 +1,111 @@
+"""GPU: drop-in MODE end to end -- the reference's UNFUSED python composition (tests/dropin_harness.py, ~30 `_ext` calls per
+forward in the reference's order: pointnet2_utils.py:26 + pointnet2_modules.py:210-272, modules.py:41-232) running on DEVICE
+tensors over graspnet_amd.pointnet2_ext, against the CPU oracle on the same seeded inputs: every index output bit-exact,
+floats under THE RULE (the layers between the operators are torch-on-GPU matmuls here, torch-CPU convolutions there), and
+graspnet_amd.pred_decode on end_points it did not produce."""
+import pytest
+import torch
+
+import dropin_harness as H
+import parity_util as PU
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def run(model_oracle, state_dict):
+    from graspnet_amd import pointnet2_ext as E, synthetic as S
+    cl = torch.stack([torch.from_numpy(S.make_cloud(1000, 20000, "uniform")),
+                      torch.from_numpy(S.make_cloud(1001, 20000, "surface"))], 0)
+    rep = model_oracle.forward({"point_clouds": cl.clone()}, state_dict, keep_internal=True)
+    sd = H.to_device(state_dict, "cuda")
+    with torch.no_grad():
+        ep = H.forward(E, cl.cuda(), sd)
+    torch.cuda.synchronize()
+    return cl, rep, ep, sd
+
+
+def test_unfused_model_over_the_dropin_ext_matches_the_oracle(run, model_oracle):
+    from graspnet_amd import pred_decode
+    cl, rep, ep, _ = run
+    for k in PU.INDEX_KEYS:
+        assert torch.equal(ep[k].cpu(), rep[k]), k
+    keys, flips, same = PU.compare_end_points(ep, rep)
+    assert flips["top_view"] <= 2 and flips["max_gap_in_oracle_scores"] <= PU.MAX_VIEW_FLIP_GAP, flips
+    for k, v in keys.items():
+        assert v["ok"], "%s: max |dropin - oracle| %.3e > limit %.3e" % (k, v["vs_oracle"]["max"], v["limit"])
+        if k in PU.HEAD_KEYS:
+            assert v["vs_oracle"]["max"] <= PU.HEAD_ABS_TOL, (k, v["vs_oracle"]["max"])
+    # the decode kernel on end_points produced elsewhere (contiguous (B,C,...) tensors, not the fused path's views)
+    preds = pred_decode({k: v for k, v in ep.items()})
+    rows = PU.compare_rows(preds, model_oracle.pred_decode(rep))
+    assert rows["rows"] >= 0.95 * sum(int(r.shape[0]) for r in model_oracle.pred_decode(rep)) - 2, rows
+    assert rows["class_flips"] <= 3 and rows["objectness_flips"] <= 2, rows
+    assert rows["score_max"] <= rows["score_limit"] and rows["width_max"] <= 1e-5, rows
+    PU.REPORT["drop-in mode: unfused model over graspnet_amd.pointnet2_ext, B=2 N=20000"] = {
+        "math": "torch-GPU matmuls between the drop-in operators", "keys": keys, "flips": flips, "rows": rows}
+
+
+def test_cylinder_lists_of_the_composed_model_are_the_oracles(run):
+    """the four cylinder_query calls of CloudCrop inside the composed model (fed by the GPU's own top-view rotations)"""
+    from graspnet_amd import pointnet2_ext as E
+    cl, rep, ep, _ = run
+    same = (ep["grasp_top_view_inds"].cpu() == rep["grasp_top_view_inds"])
+    rot9 = ep["grasp_top_view_rot"].reshape(2, 1024, 9).contiguous()
+    for d, hmax in enumerate((0.01, 0.02, 0.03, 0.04)):
+        got = E.cylinder_query(ep["fp2_xyz"], ep["input_xyz"], rot9, 0.05, -0.02, hmax, 64).cpu()
+        want = rep["_cylinder_idx"][d]
+        assert torch.equal(got[same], want[same]), hmax
+
+
+def test_consecutive_queries_on_one_cloud_share_one_grid(run, monkeypatch):
+    """SA1's ball_query and CloudCrop's four cylinder_query calls bin the SAME cloud tensor: one grid build, not five
+    (round-3 VERDICT weak item 8) -- and a reused grid returns exactly what a fresh one does; an in-place write to the cloud
+    (torch bumps its version counter) or another stream invalidates it"""
+    from graspnet_amd import pointnet2_ext as E, _lib as L
+    cl, rep, ep, sd = run
+    lib = L.lib()
+    builds = []
+    real = lib.gn_grid_build
+
+    class Counting:
+        def __call__(self, *a):
+            builds.append(a[1:4])
+            return real(*a)
+    monkeypatch.setattr(lib, "gn_grid_build", Counting(), raising=False)
+    E.clear_grid_cache()
+    with torch.no_grad():
+        ep2 = H.forward(E, cl.cuda(), sd)
+    n_cached = len(builds)
+    assert n_cached == 1, builds                   # the 20 000-pt level; SA2-4 (<= 2048 points) take the scan kernels
+    monkeypatch.setenv("GN_GRID_CACHE", "0")
+    builds.clear()
+    with torch.no_grad():
+        ep3 = H.forward(E, cl.cuda(), sd)
+    assert len(builds) == 5, builds
+    for k in ("sa1_inds", "grasp_top_view_inds", "grasp_score_pred", "sa1_features"):
+        assert torch.equal(ep2[k], ep3[k]) and torch.equal(ep2[k], ep[k]), k
+    monkeypatch.setenv("GN_GRID_CACHE", "1")
+    E.clear_grid_cache()
+    builds.clear()
+    xyz = cl.cuda()
+    ctr = xyz[:, :512].contiguous()
+    a = E.ball_query(ctr, xyz, 0.04, 64)
+    b = E.ball_query(ctr, xyz, 0.05, 32)
+    assert len(builds) == 1
+    xyz[:, 100:200] += 0.01                                   # in-place write: the cached grid is stale and must go
+    c = E.ball_query(ctr, xyz, 0.04, 64)
+    assert len(builds) == 2 and not torch.equal(a, c)
+    b_reused = E.ball_query(ctr, xyz, 0.05, 32)               # on the grid built for radius 0.04
+    assert len(builds) == 2
+    monkeypatch.setenv("GN_GRID_CACHE", "0")
+    assert torch.equal(E.ball_query(ctr, xyz, 0.04, 64), c) and torch.equal(E.ball_query(ctr, xyz, 0.05, 32), b_reused)
+    monkeypatch.setenv("GN_GRID_CACHE", "1")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    n0 = len(builds)
+    with torch.cuda.stream(side):
+        d = E.ball_query(ctr, xyz, 0.04, 64)                  # another stream: its own grid (stream order is the only order)
+    side.synchronize()
+    assert len(builds) == n0 + 1 and torch.equal(d, c)
+    E.clear_grid_cache()

@@ -202,8 +202,9 @@ def test_collision_detector_matches_reference_formula(scene, grasps):
         wcm, wem, wious = PO.collision_detect(sp, garr, approach_dist=ad, collision_thresh=0.01, voxel_size=0.005)
         assert cm.dtype == bool and np.array_equal(cm, wcm)
         assert np.array_equal(em, wem)
-        for a, b in zip(ious, wious):
-            np.testing.assert_allclose(a, b.astype(np.float32), rtol=1e-6, atol=1e-7)
+        with np.errstate(all="ignore"):
+            for a, b in zip(ious, wious):
+                assert np.array_equal(a, b.astype(np.float32), equal_nan=True)     # same integer counts, same float32 volumes
         assert 0 < cm.sum() < n          # non-trivial on this scene
     # padded / batched form with counts: padding rows are never collisions
     cm_b = det.detect_padded(g, c, approach_dist=0.05, collision_thresh=0.01)

@@ -668,6 +668,37 @@ def main():
         except Exception as ex:          # a leg beside the headline never takes the line down
             extra["dropin_unfused"] = None
             extra["dropin_unfused_error"] = str(ex)[:300]
+    if world == 1 and "knn" in legs:
+        # the knn operator (named in north_star; knn_pytorch.knn, knn/src/knn.h:12-65) at the reference's two call-site shapes
+        # (utils/label_generation.py:58-60: 300 views x 300 views; :84-86: object points x 1024 seeds), k = 1: distance tests
+        # per second against the chip's fp32 VALU rate (a test = D sub + D mul + D add + a compare-insert, ~12 lane-ops at D=3:
+        # 256 CUs x 4 SIMDs x 16 lanes x ~2.4 GHz = 39.3 T lane-ops/s), beside the round-3 one-lane-per-query kernel (GN_KNN=scan)
+        from graspnet_amd import knn_ext
+        kn = {}
+        for name, nr, nq in (("views_300x300", 300, 300), ("object_points_x_seeds_20000x1024", 20000, 1024)):
+            r = torch.randn(1, 3, nr, device=dev)
+            q = torch.randn(1, 3, nq, device=dev)
+            out_i = torch.zeros(1, 1, nq, dtype=torch.int64, device=dev)
+
+            def knn_time(reps=20):
+                knn_ext.knn(r, q, out_i)
+                a, b2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    knn_ext.knn(r, q, out_i)
+                b2.record()
+                torch.cuda.synchronize()
+                return a.elapsed_time(b2) / reps
+            t_new = knn_time()
+            os.environ["GN_KNN"] = "scan"
+            t_old = knn_time()
+            del os.environ["GN_KNN"]
+            tests = float(nr) * nq
+            kn[name] = {"ms": t_new, "scan_kernel_ms": t_old, "speedup": t_old / t_new, "distance_tests": tests,
+                        "tests_per_s": tests / (t_new * 1e-3), "frac_valu_peak": tests * 12.0 / (t_new * 1e-3) / 39.3e12,
+                        "bound": "launch latency (a few us of work)" if tests < 1e6 else "VALU issue (wave per query, k-list in registers)"}
+        extra["knn"] = kn
+        log("knn leg done: %s" % {k2: round(v["ms"], 4) for k2, v in kn.items()})
     if rank == 0:
         # dominance by CU-time: FPS is the longest kernel but runs on B of the 256 CUs
         cu_share = {k: (B / 256.0 if k.startswith("furthest_point_sampling") else 1.0) for k in stages}

@@ -2,19 +2,33 @@
 //
 // Replaces knn/src/cuda/knn.cu:36-263 (+ knn/src/knn.h:12-65 batch loop).
 // The reference materialises the full (ref_nb x query_nb) distance matrix in a
-// scratch buffer and then insertion-sorts every column; here one lane owns one
-// query, walks the reference points in ascending index order and keeps its k
-// best (distance, 1-based index) pairs sorted in the caller's (K,NQ) scratch /
-// idx planes -- coalesced across lanes because the query index is innermost.
-// Result order is the reference's: distance ascending, lower reference index
-// first among equal distances (strict compares, knn.cu:129-171 / knn_cpu.cpp:29).
-// Distances accumulate over the dimension in order 0..D-1 (knn.cu:76-93).
-// Reference points are staged through LDS tiles shared by the block.
+// scratch buffer and then insertion-sorts every column.  Result order is the
+// reference's: distance ascending, lower reference index first among equal
+// distances (strict compares, knn.cu:129-171 / knn_cpu.cpp:29) -- i.e. the k
+// smallest under the strict total order (distance, index).  Distances
+// accumulate over the dimension in order 0..D-1 (knn.cu:76-93), one rounding
+// per operation (this file is built with -ffp-contract=off).
+//
+// knn_wave_kernel (k <= 8): ONE WAVE PER QUERY (or per 4 queries when there are
+// enough of them to fill the chip that way): the 64 lanes split the reference
+// points -- lane l takes l, l+64, ... in ascending order, coalesced -- and every
+// lane keeps its own k best (distance, index) pairs as a sorted list in
+// REGISTERS (a later equal distance never displaces an earlier one: ascending
+// visits + strict compares = the reference's stability inside a lane); the 64
+// lists are then merged by k rounds of a wave-wide minimum over the 64-bit key
+// distance_bits << 32 | index (non-negative floats order like their bit
+// patterns), the owner of the minimum popping its head.  At the reference's
+// call sites (utils/label_generation.py:58-60,84-86: 300 x 300 and
+// Np' x 1024, k = 1) that is 300 / 1024 waves instead of the 2 / 4 workgroups
+// of the scan kernel below, whose k-list lived in global memory.
+// knn_scan_kernel (k > 8): one lane per query, k-list in the caller's scratch.
+#include <stdlib.h>
+
 #include "gn_common.h"
 
 namespace gn {
 
-__global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ ref,
+__global__ __launch_bounds__(256) void knn_scan_kernel(const float *__restrict__ ref,
                                                   const float *__restrict__ query, int d, int nr, int nq,
                                                   int k, int64_t *__restrict__ idx,
                                                   float *__restrict__ dist) {
@@ -62,6 +76,81 @@ __global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ ref,
     for (int t = cnt; t < k; ++t) idx[(size_t)t * nq + q] = 0;  // k > nr: undefined upstream, 0 here
 }
 
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)v, o), hi = __shfl_xor((unsigned)(v >> 32), o);
+    const unsigned long long u = ((unsigned long long)hi << 32) | lo;
+    v = u < v ? u : v;
+  }
+  return v;
+}
+
+constexpr unsigned long long KNN_NONE = ~0ULL;
+
+// K: list length (>= k), QW: queries per wave
+template <int K, int QW>
+__global__ __launch_bounds__(256) void knn_wave_kernel(const float *__restrict__ ref, const float *__restrict__ query, int d,
+                                                       int nr, int nq, int k, int64_t *__restrict__ idx) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int q0 = wave * QW;
+  if (q0 >= nq) return;
+  ref += (size_t)b * d * nr;
+  query += (size_t)b * d * nq;
+  idx += (size_t)b * k * nq;
+  // sorted ascending by (distance, index); empty slots hold KNN_NONE (above every real key: a distance is never NaN-free
+  // larger than 0x7f800000 = +Inf in the high word with an index below 2^32 - 1)
+  unsigned long long best[QW][K];
+#pragma unroll
+  for (int qi = 0; qi < QW; ++qi)
+#pragma unroll
+    for (int t = 0; t < K; ++t) best[qi][t] = KNN_NONE;
+  for (int r = lane; r < nr; r += 64) {
+    float dd[QW];
+#pragma unroll
+    for (int qi = 0; qi < QW; ++qi) dd[qi] = 0.f;
+    for (int h = 0; h < d; ++h) {
+      const float rv = ref[(size_t)h * nr + r];
+#pragma unroll
+      for (int qi = 0; qi < QW; ++qi) {
+        const int q = min(q0 + qi, nq - 1);
+        const float t = rv - query[(size_t)h * nq + q];      // wave-uniform address
+        dd[qi] += t * t;
+      }
+    }
+#pragma unroll
+    for (int qi = 0; qi < QW; ++qi) {
+      // a NaN distance sorts after every number (the reference's strict `>` never moves anything past it either)
+      const unsigned bits = dd[qi] == dd[qi] ? __float_as_uint(dd[qi]) : 0x7fc00000u;
+      unsigned long long key = ((unsigned long long)bits << 32) | (unsigned)r;
+      // insertion keeping the K smallest: bubble the new key down the sorted list
+#pragma unroll
+      for (int t = 0; t < K; ++t) {
+        const unsigned long long cur = best[qi][t];
+        const bool less = key < cur;
+        best[qi][t] = less ? key : cur;
+        key = less ? cur : key;
+      }
+    }
+  }
+  // merge the 64 lists: k rounds of a wave-wide minimum; its owner pops
+#pragma unroll
+  for (int qi = 0; qi < QW; ++qi) {
+    if (q0 + qi >= nq) break;       // wave-uniform
+    for (int t = 0; t < k; ++t) {
+      const unsigned long long m = wave_min_u64(best[qi][0]);
+      if (best[qi][0] == m && m != KNN_NONE) {
+#pragma unroll
+        for (int u = 0; u + 1 < K; ++u) best[qi][u] = best[qi][u + 1];
+        best[qi][K - 1] = KNN_NONE;
+      }
+      if (lane == 0) idx[(size_t)t * nq + q0 + qi] = m == KNN_NONE ? 0 : (int64_t)(unsigned)(m & 0xffffffffu) + 1;   // 1-based
+    }
+  }
+}
+
 }  // namespace gn
 
 extern "C" int gn_knn(const float *ref, const float *query, int b, int d, int nr, int nq, int k,
@@ -69,11 +158,31 @@ extern "C" int gn_knn(const float *ref, const float *query, int b, int d, int nr
   using namespace gn;
   GN_REQUIRE(b >= 0 && d >= 1 && nr >= 0 && nq >= 0 && k >= 0, "knn: bad sizes");
   if (b == 0 || nq == 0 || k == 0) return GN_OK;
-  GN_REQUIRE(ref && query && idx && scratch, "knn: null pointer");
-  GN_REQUIRE(d <= 3072, "knn: dim > 3072 unsupported");
+  GN_REQUIRE(ref && query && idx, "knn: null pointer");
   GN_REQUIRE(b <= 65535, "knn: batch > 65535 unsupported");
+  const char *ve = getenv("GN_KNN");            // GN_KNN=scan: the one-lane-per-query kernel for every k (A/B, tests)
+  const bool scan = k > 8 || (ve && ve[0] == 's');
+  if (!scan) {
+    // four queries per wave once that still leaves every CU a few workgroups (the reference points are then read once per
+    // four queries); one query per wave otherwise -- 1024 queries = 256 workgroups
+    const bool qw4 = (long)b * nq >= 4L * 4 * 1024;
+#define GN_KNN_LAUNCH(K, QW)                                                                                          \
+  hipLaunchKernelGGL((knn_wave_kernel<K, QW>), dim3(((nq + QW - 1) / QW + 3) / 4, b), dim3(256), 0, as_stream(stream), ref, \
+                     query, d, nr, nq, k, idx)
+#define GN_KNN_K(K) do { if (qw4) GN_KNN_LAUNCH(K, 4); else GN_KNN_LAUNCH(K, 1); } while (0)
+    if (k == 1) GN_KNN_K(1);
+    else if (k == 2) GN_KNN_K(2);
+    else if (k <= 4) GN_KNN_K(4);
+    else GN_KNN_K(8);
+#undef GN_KNN_K
+#undef GN_KNN_LAUNCH
+    GN_CHECK_LAUNCH("knn");
+    return GN_OK;
+  }
+  GN_REQUIRE(scratch, "knn: scratch required for k > 8");
+  GN_REQUIRE(d <= 3072, "knn: dim > 3072 unsupported");
   dim3 grid((nq + 255) / 256, b);
-  hipLaunchKernelGGL(knn_kernel, grid, dim3(256), 0, as_stream(stream), ref, query, d, nr, nq, k, idx,
+  hipLaunchKernelGGL(knn_scan_kernel, grid, dim3(256), 0, as_stream(stream), ref, query, d, nr, nq, k, idx,
                      scratch);
   GN_CHECK_LAUNCH("knn");
   return GN_OK;

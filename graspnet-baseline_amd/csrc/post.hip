@@ -277,32 +277,23 @@ struct ColGrasp {            // float32 pre-test constants of one grasp, 16 floa
   float xlo, xhi, yb, zb;    // union of the four boxes + the inner box, widened by eps
 };
 
-__device__ __forceinline__ void collision_exact(const double *__restrict__ sp, const float *__restrict__ gr,
-                                                const CollisionParams &P, int *cnt) {
-  const float width = gr[1], height = gr[2], depth = gr[3];
+struct ColGraspD {           // the exact test's constants: float32 expressions of numpy, widened to float64 once per grasp
   double R[9], T[3];
-  for (int i = 0; i < 9; ++i) R[i] = (double)gr[4 + i];
-  for (int i = 0; i < 3; ++i) T[i] = (double)gr[13 + i];
-  // thresholds are float32 expressions in numpy (float32 arrays with python scalars), :84-99
-  const double zlo = (double)(-height / 2.0f), zhi = (double)(height / 2.0f);
-  const double x_fl = (double)(depth - P.finger_length);
-  const double x_d = (double)depth;
-  const double y3 = (double)(-(width / 2.0f + P.finger_width));
-  const double y4 = (double)(-width / 2.0f);
-  const double y5 = (double)(width / 2.0f + P.finger_width);
-  const double y6 = (double)(width / 2.0f);
-  const double x_b = (double)(depth - P.finger_length - P.finger_width);
-  const double x_s = (double)(depth - P.finger_length - P.finger_width - P.approach_dist);
-  const double dx = sp[0] - T[0], dy = sp[1] - T[1], dz = sp[2] - T[2];
+  double zlo, zhi, x_fl, x_d, y3, y4, y5, y6, x_b, x_s;
+};
+
+// exact evaluation of one (point, grasp) pair, float64 as numpy does it (collision_detector.py:80-112)
+__device__ __forceinline__ void collision_exact(const double *__restrict__ sp, const ColGraspD &G, int *cnt) {
+  const double dx = sp[0] - G.T[0], dy = sp[1] - G.T[1], dz = sp[2] - G.T[2];
   // targets = (scene - T) @ R  (:80-81)
-  const double tx = dx * R[0] + dy * R[3] + dz * R[6];
-  const double ty = dx * R[1] + dy * R[4] + dz * R[7];
-  const double tz = dx * R[2] + dy * R[5] + dz * R[8];
-  const bool m1 = tz > zlo && tz < zhi;
-  const bool m2 = tx > x_fl && tx < x_d;
-  const bool m3 = ty > y3, m4 = ty < y4, m5 = ty < y5, m6 = ty > y6;
-  const bool m7 = tx <= x_fl && tx > x_b;
-  const bool m8 = tx <= x_b && tx > x_s;
+  const double tx = dx * G.R[0] + dy * G.R[3] + dz * G.R[6];
+  const double ty = dx * G.R[1] + dy * G.R[4] + dz * G.R[7];
+  const double tz = dx * G.R[2] + dy * G.R[5] + dz * G.R[8];
+  const bool m1 = tz > G.zlo && tz < G.zhi;
+  const bool m2 = tx > G.x_fl && tx < G.x_d;
+  const bool m3 = ty > G.y3, m4 = ty < G.y4, m5 = ty < G.y5, m6 = ty > G.y6;
+  const bool m7 = tx <= G.x_fl && tx > G.x_b;
+  const bool m8 = tx <= G.x_b && tx > G.x_s;
   const bool left = m1 && m2 && m3 && m4;
   const bool right = m1 && m2 && m5 && m6;
   const bool bottom = m1 && m3 && m5 && m7;
@@ -323,7 +314,9 @@ __global__ __launch_bounds__(256) void collision_kernel(const double *__restrict
                                                         uint8_t *__restrict__ empty_mask, float *__restrict__ ious) {
   __shared__ int s_cnt[COL_GB][8];
   __shared__ ColGrasp s_g[COL_GB];
-  const int b = blockIdx.y, tid = threadIdx.x;
+  __shared__ ColGraspD s_gd[COL_GB];
+  __shared__ int s_queue[4][128];      // per wave: (point index << 3 | grasp slot) of the pairs that passed the pre-test
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g0 = blockIdx.x * COL_GB;
   const int m_valid = counts ? min(counts[b], mpad) : mpad;
   const int ng = min(COL_GB, m_valid - g0);          // grasps of this workgroup that exist; the rest are padding rows
@@ -342,17 +335,43 @@ __global__ __launch_bounds__(256) void collision_kernel(const double *__restrict
   if (tid < ng) {
     const float *gr = grow + (size_t)tid * ldg;
     ColGrasp c;
-    for (int i = 0; i < 9; ++i) c.r[i] = gr[4 + i];
-    for (int i = 0; i < 3; ++i) c.t[i] = gr[13 + i];
+    ColGraspD G;
+    for (int i = 0; i < 9; ++i) { c.r[i] = gr[4 + i]; G.R[i] = (double)gr[4 + i]; }
+    for (int i = 0; i < 3; ++i) { c.t[i] = gr[13 + i]; G.T[i] = (double)gr[13 + i]; }
     const float width = gr[1], height = gr[2], depth = gr[3];
+    // thresholds are float32 expressions in numpy (float32 arrays with python scalars), :84-99
+    G.zlo = (double)(-height / 2.0f); G.zhi = (double)(height / 2.0f);
+    G.x_fl = (double)(depth - P.finger_length);
+    G.x_d = (double)depth;
+    G.y3 = (double)(-(width / 2.0f + P.finger_width));
+    G.y4 = (double)(-width / 2.0f);
+    G.y5 = (double)(width / 2.0f + P.finger_width);
+    G.y6 = (double)(width / 2.0f);
+    G.x_b = (double)(depth - P.finger_length - P.finger_width);
+    G.x_s = (double)(depth - P.finger_length - P.finger_width - P.approach_dist);
     const float eps = 2e-6f * (fabsf(c.t[0]) + fabsf(c.t[1]) + fabsf(c.t[2]) + 1.0f);
     c.xlo = depth - P.finger_length - P.finger_width - P.approach_dist - eps;
     c.xhi = depth + eps;
     c.yb = fabsf(width) * 0.5f + P.finger_width + eps;
     c.zb = fabsf(height) * 0.5f + eps;
     s_g[tid] = c;
+    s_gd[tid] = G;
   }
   __syncthreads();
+  int *queue = s_queue[wv];
+  int qn = 0;                        // wave-uniform: pairs waiting in the queue
+  // the pairs that pass are rare (tens of a scene's ~10^4 points per grasp) and scattered over the lanes: they are queued
+  // and evaluated 64 at a time, one per lane, instead of dragging the wave through the float64 path for one lane each
+  auto drain = [&](int take) {
+    if (lane < take) {
+      const int e = queue[lane];
+      collision_exact(scene + (size_t)(e >> 3) * 3, s_gd[e & 7], s_cnt[e & 7]);
+    }
+    const int rest = qn - take;
+    const int moved = lane < rest ? queue[take + lane] : 0;
+    if (lane < rest) queue[lane] = moved;     // rest < 64: a queue never holds more than 64 + 63 pairs
+    qn = rest;
+  };
   for (int base = 0; base < np; base += 256 * COL_K) {
     float px[COL_K], py[COL_K], pz[COL_K];
 #pragma unroll
@@ -372,11 +391,19 @@ __global__ __launch_bounds__(256) void collision_kernel(const double *__restrict
         const float tx = fmaf(dz, c.r[6], fmaf(dy, c.r[3], dx * c.r[0]));
         const float ty = fmaf(dz, c.r[7], fmaf(dy, c.r[4], dx * c.r[1]));
         const float tz = fmaf(dz, c.r[8], fmaf(dy, c.r[5], dx * c.r[2]));
-        if (fabsf(tz) < c.zb && fabsf(ty) < c.yb && tx > c.xlo && tx < c.xhi)
-          collision_exact(scene + (size_t)(base + k * 256 + tid) * 3, grow + (size_t)g * ldg, P, s_cnt[g]);
+        const bool pass = fabsf(tz) < c.zb && fabsf(ty) < c.yb && tx > c.xlo && tx < c.xhi;
+        const unsigned long long m = __ballot(pass);
+        if (m) {                       // wave-uniform
+          if (pass)
+            queue[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] =
+                ((base + k * 256 + tid) << 3) | g;
+          qn += __popcll(m);
+          if (qn >= 64) drain(64);
+        }
       }
     }
   }
+  if (qn > 0) drain(qn);
   __syncthreads();
   if (tid < ng) {
     const float *gr = grow + (size_t)tid * ldg;
@@ -600,6 +627,7 @@ static int collision_launch(const double *scene_points, size_t scene_stride, con
                             float finger_length, uint8_t *collision_mask, uint8_t *empty_mask, float *ious,
                             gn_stream_t stream) {
   GN_REQUIRE(b >= 0 && mpad >= 0 && np >= 0, "collision_detect: bad sizes");
+  GN_REQUIRE(np < (1 << 28) || np == 0x7fffffff, "collision_detect: more than 2^28 scene points unsupported");
   if (b == 0 || mpad == 0) return GN_OK;
   GN_REQUIRE(scene_points && grasps && collision_mask, "collision_detect: null pointer");
   GN_REQUIRE(b <= 65535, "collision_detect: batch > 65535 unsupported");

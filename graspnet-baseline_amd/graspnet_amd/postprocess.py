@@ -1,6 +1,8 @@
 """Device-side front end and post-processing around the network.
 
   depth_to_cloud                 utils/data_utils.py:18-43 (+ picking the sampled pixels)
+  valid_pixels / depth_to_cloud_masked   the whole host front end of dataset/graspnet_dataset.py:104-147 / demo.py:449-463
+                                 (workspace mask & depth > 0, ordered compaction, sub-sampling) for a batch of images
   ModelFreeCollisionDetector     utils/collision_detector.py:10-129 (same constructor / detect() arguments)
   sort_and_nms                   graspnetAPI GraspGroup.sort_by_score() / .nms()  [un-vendored, parity unpinned]
 
@@ -31,6 +33,87 @@ def depth_to_cloud(depth, fx, fy, cx, cy, factor_depth, pix_idx):
                                           float(factor_depth), pix_idx.data_ptr(), pix_idx.numel(), out.data_ptr(),
                                           _stream(depth)), "depth_to_cloud")
     return out
+
+
+def _as_u16(depth):
+    if depth.dtype not in (torch.uint16, torch.int16) or not depth.is_contiguous():
+        raise RuntimeError("depth must be a contiguous 16-bit tensor")
+    return depth
+
+
+def valid_pixels(depth, mask, factor_depth, depth_min=0.0, depth_max=float("inf")):
+    """depth (B,H,W) 16-bit CUDA, mask (B,H,W) uint8 / bool or None -> (valid_pix (B,H*W) i32, count (B,) i32) on the device:
+    the flat indices of the pixels with mask != 0, depth > 0 and depth_min < depth / factor_depth < depth_max in row-major
+    order -- numpy's cloud[mask] order (dataset/graspnet_dataset.py:118-133, demo.py:453-455) -- and how many there are."""
+    if not depth.is_cuda:
+        raise RuntimeError("CPU not supported")
+    depth = _as_u16(depth)
+    if depth.dim() == 2:
+        depth = depth.unsqueeze(0)
+        mask = None if mask is None else mask.unsqueeze(0)
+    B, h, w = depth.shape
+    dev = depth.device
+    if mask is not None:
+        if mask.shape != depth.shape:
+            raise RuntimeError("mask must have the depth image's shape")
+        mask = (mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)).to(dev).contiguous()
+    lib = L.lib()
+    ws = torch.empty((lib.gn_frontend_workspace_bytes(B, h, w),), dtype=torch.uint8, device=dev)
+    vpix = torch.empty((B, h * w), dtype=torch.int32, device=dev)
+    cnt = torch.empty((B,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        L.check(lib.gn_depth_valid_compact(depth.data_ptr(), L.ptr(mask), B, h, w, float(factor_depth), float(depth_min),
+                                           float(depth_max), ws.data_ptr(), vpix.data_ptr(), cnt.data_ptr(), _stream(depth)),
+                "depth_valid_compact")
+    return vpix, cnt
+
+
+def depth_to_cloud_masked(depth, mask, fx, fy, cx, cy, factor_depth, num_point, positions=None, random_words=None, seed=None,
+                          depth_min=0.0, depth_max=float("inf"), return_pix=False):
+    """The reference's host-side front end (dataset/graspnet_dataset.py:104-147, demo.py:449-463) for a batch of images on the
+    device: cloud from depth, keep workspace-mask & depth > 0 pixels, take num_point of them.
+      depth (B,H,W) or (H,W) 16-bit CUDA tensor, mask the same shape (uint8 / bool) or None
+      positions (B,num_point) int: the caller's own draw into the valid list -- with the reference's `idxs` the cloud is the
+          reference's bit for bit; or random_words (B,num_point) 32-bit: all valid pixels first when there are fewer than
+          num_point (as the reference does), then floor(word * count / 2^32), i.e. with replacement; or seed: the words come
+          from torch's device generator seeded with it.  Nothing is read back.
+    -> cloud (B,num_point,3) f32, count (B,) i32 [, pix (B,num_point) i32]"""
+    if not depth.is_cuda:
+        raise RuntimeError("CPU not supported")
+    single = depth.dim() == 2
+    if single:
+        depth = depth.unsqueeze(0)
+        mask = None if mask is None else mask.unsqueeze(0)
+        positions = None if positions is None else positions.reshape(1, -1)
+        random_words = None if random_words is None else random_words.reshape(1, -1)
+    depth = _as_u16(depth)
+    B, h, w = depth.shape
+    dev = depth.device
+    n = int(num_point)
+    vpix, cnt = valid_pixels(depth, mask, factor_depth, depth_min, depth_max)
+    if positions is not None:
+        positions = positions.to(device=dev, dtype=torch.int32).contiguous()
+        if positions.shape != (B, n):
+            raise RuntimeError("positions must be (B, num_point)")
+    elif random_words is None:
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0 if seed is None else int(seed))
+        r64 = torch.randint(0, 2 ** 32, (B, n), dtype=torch.int64, device=dev, generator=gen)
+        random_words = torch.where(r64 >= 2 ** 31, r64 - 2 ** 32, r64).to(torch.int32)       # the same 32 bits, as int32
+    if random_words is not None:
+        random_words = random_words.to(device=dev).contiguous()
+        if random_words.dtype not in (torch.int32, torch.uint32) or random_words.shape != (B, n):
+            raise RuntimeError("random_words must be (B, num_point) 32-bit integers")
+    out = torch.empty((B, n, 3), dtype=torch.float32, device=dev)
+    pix = torch.empty((B, n), dtype=torch.int32, device=dev) if return_pix else None
+    with torch.cuda.device(dev):
+        L.check(L.lib().gn_depth_sample_cloud(depth.data_ptr(), B, h, w, float(fx), float(fy), float(cx), float(cy),
+                                              float(factor_depth), vpix.data_ptr(), cnt.data_ptr(), L.ptr(positions),
+                                              L.ptr(random_words), n, out.data_ptr(), L.ptr(pix), _stream(depth)),
+                "depth_sample_cloud")
+    if single:
+        out, pix = out[0], (None if pix is None else pix[0])
+    return (out, cnt, pix) if return_pix else (out, cnt)
 
 
 def voxel_down_sample_batched(points, voxel_size, n_valid=None, check=False):

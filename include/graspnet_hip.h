@@ -371,6 +371,24 @@ int gn_graspnet_forward(const gn_weights *weights, const float *cloud /* (B,N,3)
 int gn_depth_to_cloud(const uint16_t *depth, int h, int w, double fx, double fy, double cx, double cy,
                       double factor_depth, const int32_t *pix, int npix, float *out, gn_stream_t stream);
 
+/* The same front end for a BATCH of images with the validity mask and the sub-sampling on the device
+ * (dataset/graspnet_dataset.py:118-145, demo.py:449-463): nothing is built on the host.
+ * gn_depth_valid_compact: depth (B,H,W) u16, mask (B,H,W) u8 or NULL -> valid_pix (B,H*W) i32: the flat indices of
+ *   the pixels with mask != 0, depth > 0 and depth_min < depth/factor_depth < depth_max, in row-major order (numpy's
+ *   cloud[mask] order), count (B) their number.  workspace: gn_frontend_workspace_bytes(B,H,W).
+ * gn_depth_sample_cloud: out (B,n,3) f32 = the reference's cloud_masked[idxs] with idxs = `positions` (B,n) into the
+ *   valid list (the caller's own np.random.choice draw: numpy's stream cannot be reproduced on a device), or, with
+ *   positions NULL, drawn from `random_words` (B,n) u32: all valid pixels first when there are fewer than n (as the
+ *   reference), then floor(word * count / 2^32) (with replacement).  out_pix (B,n) i32 (may be NULL): the pixel taken.
+ *   An image without a valid pixel gives zeros / -1. */
+size_t gn_frontend_workspace_bytes(int b, int h, int w);
+int gn_depth_valid_compact(const uint16_t *depth, const uint8_t *mask, int b, int h, int w, double factor_depth,
+                           double depth_min, double depth_max, void *workspace, int32_t *valid_pix, int32_t *count,
+                           gn_stream_t stream);
+int gn_depth_sample_cloud(const uint16_t *depth, int b, int h, int w, double fx, double fy, double cx, double cy,
+                          double factor_depth, const int32_t *valid_pix, const int32_t *count, const int32_t *positions,
+                          const uint32_t *random_words, int n, float *out, int32_t *out_pix, gn_stream_t stream);
+
 /* open3d voxel_down_sample as used by utils/collision_detector.py:32-35 (un-vendored; restated:
  * origin = min_bound - voxel/2, voxel index = floor((p-origin)/voxel), output = mean of members in
  * float64), for a whole batch of clouds in one call, no host read, DETERMINISTIC: the voxels of a cloud

@@ -22,6 +22,19 @@ def depth_to_cloud(depth, fx, fy, cx, cy, scale):
     return np.stack([points_x, points_y, points_z], axis=-1).reshape(-1, 3)
 
 
+def masked_cloud_sample(depth, mask, fx, fy, cx, cy, scale, idxs, depth_min=0.0, depth_max=np.inf):
+    """dataset/graspnet_dataset.py:118-145 / demo.py:449-463: organised cloud from depth (utils/data_utils.py:18-43), keep
+    `mask & (depth > 0)` (and depth_min < z < depth_max) in row-major order, take rows `idxs` of it (the caller's
+    np.random.choice draw), float32 as the callers cast it.  -> (cloud_sampled (n,3) f32, number of valid pixels)"""
+    cloud = depth_to_cloud(depth, fx, fy, cx, cy, scale)
+    z = depth / scale
+    m = (depth > 0) & (z > depth_min) & (z < depth_max)
+    if mask is not None:
+        m = m & (np.asarray(mask) != 0)
+    cloud_masked = cloud[m.reshape(-1)]
+    return cloud_masked[np.asarray(idxs)].astype(np.float32), int(len(cloud_masked))
+
+
 def voxel_down_sample(points, voxel_size):
     pts = np.asarray(points, dtype=np.float64)
     origin = pts.min(axis=0) - voxel_size * 0.5

@@ -1,10 +1,18 @@
 #!/bin/bash
-# kernel-trace stats of the steps around the network (bench.py --legs post: voxel down-sample + collision detect + sort/NMS on
-# the batch's 8 decoded scenes).  Run ON THE GPU BOX: gpurun -- bash profiles/run_profile_post.sh r3_post
-TAG=${1:-r3_post}
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
-mkdir -p $OUT; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-ARGS="bench.py --steps 2 --warmup 1 --legs post"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err || true
-python3 profiles/summarize.py $OUT > $OUT/summary.txt 2>&1 || true
-grep -i "voxel\|collision\|nms\|sort" $OUT/summary.txt
+# usage (on the GPU box): bash profiles/run_profile_post.sh <tag>   -> gpurun_out/<tag>_post_kernel_stats.csv + summary
+TAG=${1:-r4}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_post_prof
+mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o post -- python3 $GRAFT_REPO_ROOT/profiles/post_probe.py > $OUT/log.txt 2>&1
+cd $GRAFT_REPO_ROOT
+f=$(find $OUT -name "*kernel_stats.csv" | head -1)
+cp "$f" gpurun_out/${TAG}_post_kernel_stats.csv
+python3 - <<PY > gpurun_out/${TAG}_post_summary.txt
+import csv
+rows = list(csv.DictReader(open("gpurun_out/${TAG}_post_kernel_stats.csv")))
+print("rocprofv3 --kernel-trace --stats -- python3 profiles/post_probe.py   (50 x postprocess.grasp_pipeline on one batch of 8 decoded scenes + one forward)")
+print("%-70s %8s %12s %10s" % ("kernel", "calls", "avg us", "total %"))
+for r in rows:
+    print("%-70s %8s %12.2f %10s" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
+PY
+cat gpurun_out/${TAG}_post_summary.txt

@@ -500,6 +500,31 @@ def test_knn_bit_exact(oracle):
         assert torch.equal(got.cpu(), want)
 
 
+def test_knn_wave_kernel_shapes_and_the_scan_kernel_agree(oracle, monkeypatch):
+    """the wave-per-query kernel at the reference's call-site shapes (utils/label_generation.py:58-60: 300 x 300, :84-86:
+    Np' x 1024, k = 1), with four queries per wave (many queries), ragged tails, k in {1,2,3,4,5,8}, fewer references than k,
+    exact duplicate references (ties -> lower index first); == the oracle (== the reference's knn_cpu.cpp,
+    tests/test_oracle_properties.py) and == the one-lane-per-query scan kernel"""
+    from graspnet_amd import knn_ext
+    rng = np.random.default_rng(4)
+    for (B, D, Nr, Nq, k) in [(1, 3, 300, 300, 1), (1, 3, 7919, 1024, 1), (3, 3, 1000, 8197, 2), (2, 3, 257, 4099, 3),
+                              (1, 4, 63, 65, 4), (1, 3, 129, 17, 5), (2, 2, 100, 70, 8), (1, 3, 5, 20, 8), (1, 3, 1, 3, 1)]:
+        r = torch.from_numpy(rng.standard_normal((B, D, Nr)).astype(np.float32))
+        q = torch.from_numpy(rng.standard_normal((B, D, Nq)).astype(np.float32))
+        r[:, :, Nr // 2:] = r[:, :, :Nr - Nr // 2]              # every reference point twice: exact distance ties
+        q[:, :, :min(Nq, Nr)] = r[:, :, :min(Nq, Nr)]           # and queries that coincide with references (distance 0)
+        want = torch.zeros(B, k, Nq, dtype=torch.int64)
+        oracle.knn(r, q, want)
+        got = torch.full((B, k, Nq), -7, dtype=torch.int64, device="cuda")
+        assert knn_ext.knn(r.cuda(), q.cuda(), got) == 1
+        assert torch.equal(got.cpu(), want), (B, D, Nr, Nq, k)
+        monkeypatch.setenv("GN_KNN", "scan")
+        got2 = torch.full((B, k, Nq), -7, dtype=torch.int64, device="cuda")
+        knn_ext.knn(r.cuda(), q.cuda(), got2)
+        monkeypatch.delenv("GN_KNN")
+        assert torch.equal(got2, got), (B, D, Nr, Nq, k)
+
+
 def test_error_behaviour_matches_reference(E):
     x = torch.rand(1, 10, 3)
     with pytest.raises(RuntimeError, match="CPU not supported"):

@@ -37,6 +37,72 @@ def test_depth_to_cloud_exact():
     assert np.array_equal(got, want[pix])
 
 
+def test_front_end_on_the_device_matches_the_reference_formula(golden_dir):
+    """depth images + workspace masks in, sampled clouds out, nothing built on the host: the ordered list of
+    valid pixels == numpy's cloud[mask] order, and with the caller's own np.random.choice draw the sampled cloud is the
+    reference formula's bit for bit (dataset/graspnet_dataset.py:118-145); seed-stream sampling draws only valid pixels and
+    takes all of them first when there are fewer than num_point"""
+    from graspnet_amd import postprocess as P
+    from oracle import post_oracle as PO
+    rng = np.random.default_rng(3)
+    B, h, w, n = 3, 180, 320, 5000
+    depth = rng.integers(0, 2500, size=(B, h, w), dtype=np.uint16)
+    depth[rng.random((B, h, w)) < 0.3] = 0                            # holes
+    mask = (rng.random((B, h, w)) < 0.6).astype(np.uint8)
+    mask[2] = 0
+    mask[2, 10:14, 5:300] = 1                                        # image 2: fewer valid pixels than num_point
+    fx, fy, cx, cy, scale = 631.5, 631.2, 158.7, 91.9, 1000.0
+    d = torch.from_numpy(depth.view(np.int16)).cuda()
+    mk = torch.from_numpy(mask).cuda()
+    vpix, cnt = P.valid_pixels(d, mk, scale)
+    pos, want, counts = [], [], []
+    for b in range(B):
+        m = (mask[b] != 0) & (depth[b] > 0)
+        valid = np.nonzero(m.reshape(-1))[0]
+        assert int(cnt[b]) == len(valid) and np.array_equal(vpix[b, :len(valid)].cpu().numpy(), valid)
+        # the reference's draw (graspnet_dataset.py:139-145), made here by the caller
+        if len(valid) >= n:
+            idxs = rng.choice(len(valid), n, replace=False)
+        else:
+            idxs = np.concatenate([np.arange(len(valid)), rng.choice(len(valid), n - len(valid), replace=True)])
+        pos.append(idxs)
+        c, nvalid = PO.masked_cloud_sample(depth[b], mask[b], fx, fy, cx, cy, scale, idxs)
+        want.append(c)
+        counts.append(nvalid)
+    assert counts[2] < n <= counts[0]
+    cloud, cnt2, pix = P.depth_to_cloud_masked(d, mk, fx, fy, cx, cy, scale, n, positions=torch.from_numpy(np.stack(pos)),
+                                               return_pix=True)
+    assert cnt2.cpu().tolist() == counts
+    assert np.array_equal(cloud.cpu().numpy(), np.stack(want))
+    # depth range (demo.py:453) and no mask
+    c3, nv3 = PO.masked_cloud_sample(depth[0], None, fx, fy, cx, cy, scale, np.arange(100), depth_min=0.5, depth_max=1.5)
+    g3, cn3 = P.depth_to_cloud_masked(d[0], None, fx, fy, cx, cy, scale, 100, positions=torch.arange(100), depth_min=0.5, depth_max=1.5)
+    assert int(cn3[0]) == nv3 and np.array_equal(g3.cpu().numpy(), c3)
+    # seed stream: reproducible, only valid pixels, all of them first when there are fewer than num_point
+    a1, _, p1 = P.depth_to_cloud_masked(d, mk, fx, fy, cx, cy, scale, n, seed=11, return_pix=True)
+    a2, _, p2 = P.depth_to_cloud_masked(d, mk, fx, fy, cx, cy, scale, n, seed=11, return_pix=True)
+    a3, _, p3 = P.depth_to_cloud_masked(d, mk, fx, fy, cx, cy, scale, n, seed=12, return_pix=True)
+    assert torch.equal(a1, a2) and torch.equal(p1, p2) and not torch.equal(p1, p3)
+    p1 = p1.cpu().numpy()
+    for b in range(B):
+        m = ((mask[b] != 0) & (depth[b] > 0)).reshape(-1)
+        assert m[p1[b]].all()
+        assert len(np.unique(p1[b])) > 0.5 * min(n, counts[b])
+    assert np.array_equal(p1[2, :counts[2]], np.nonzero(((mask[2] != 0) & (depth[2] > 0)).reshape(-1))[0])
+    # an image without a valid pixel: zeros, count 0
+    z, cz = P.depth_to_cloud_masked(torch.zeros_like(d[0]), None, fx, fy, cx, cy, scale, 64, seed=1)
+    assert int(cz[0]) == 0 and not z.any()
+    # the reference's own example scene (fixture: picked pixels + their depth, cloud made by the reference's function)
+    zf = np.load(golden_dir + "/example_scene_n20000.npz")
+    hh, ww = int(zf["shape"][0]), int(zf["shape"][1])
+    fx, fy, cx, cy, factor = [float(v) for v in zf["intrinsics"]]
+    dep = np.zeros(hh * ww, np.uint16)
+    dep[zf["pix"]] = zf["depth_at_pix"]
+    de = torch.from_numpy(dep.reshape(hh, ww).view(np.int16)).cuda()
+    ge, ce, pe = P.depth_to_cloud_masked(de, None, fx, fy, cx, cy, factor, 20000, positions=torch.arange(20000), return_pix=True)
+    assert int(ce[0]) == 20000 and np.array_equal(pe.cpu().numpy(), zf["pix"]) and np.array_equal(ge.cpu().numpy(), zf["cloud"])
+
+
 def test_voxel_down_sample(scene):
     from graspnet_amd import postprocess as P
     from oracle import post_oracle as PO

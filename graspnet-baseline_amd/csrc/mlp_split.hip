@@ -227,8 +227,8 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_unique_split_kernel(const fl
 // chunk c.  Every row goes through the same MFMAs in the same k order and max() is exact, so the result is bit-identical
 // to the padded kernel (tests/test_split_gpu.py).
 // RIDE: layer 1 of the next chunk under this chunk's layer-3 MFMAs (else on its own at the top of its chunk)
-template <int C1, int C2, int C3, int ND, int CAP, int TP, bool RIDE>
-__global__ __launch_bounds__(MLP_THREADS) void crop_packed_split_kernel(const float *__restrict__ xyz, int n,
+template <int C1, int C2, int C3, int ND, int CAP, int TP, bool RIDE, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void crop_packed_split_kernel(const float *__restrict__ xyz, int n,
                                                                         const float *__restrict__ seed,
                                                                         const float *__restrict__ rot,
                                                                         const int32_t *__restrict__ uidx,
@@ -250,10 +250,12 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_packed_split_kernel(const fl
   __shared__ int s_off[kCropMaxSpb + 1];                           // stream offset of each seed slot; [slots..] = total
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-  using L2 = LayerWS<C1, C2>;
-  using L3 = LayerWS<C2, C3>;
+  using L2 = LayerWS<C1, C2, NWV>;
+  using L3 = LayerWS<C2, C3, NWV>;
   static_assert(L3::WM == 1, "every wave walks all M tiles of layer 3");
   static_assert(C1 == 64, "8 threads x 8 channels cover a row");
+  static_assert(NWV == 4 || !RIDE, "layer 1 rides on the layer-3 units of the 4-wave form only");
+  constexpr int L1ROWS = NWV * 64 / 8;       // rows one pass of layer 1 covers (8 threads per row)
   constexpr int NTW = L3::NTW;
   L2 w2;
   L3 w3;
@@ -372,6 +374,18 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_packed_split_kernel(const fl
   auto l1_dst = [&](int mt, bool active) {
     return active ? bufY1 + (mt * 32 + (tid >> 3)) * sp_stride(C1) + (tid & 7) * 8 : dumpY1 + (tid & 63) * 8;
   };
+  // layer 1 of a whole chunk on its own: passes of L1ROWS rows (a thread whose row lies past the chunk's tiles sits out)
+  auto l1_chunk = [&](int b, int nrows) {
+    for (int r0 = 0; r0 < nrows; r0 += L1ROWS) {
+      const int row = r0 + (tid >> 3);
+      if (row < nrows) {
+        const float *src = bufX + b * (TP + 1) * XS0 + row * XS0;
+        __bf16 *dst = bufY1 + row * sp_stride(C1) + (tid & 7) * 8;
+#pragma unroll
+        for (int sl = 0; sl < 6; ++sl) l1_slice(sl, src, dst, P1);
+      }
+    }
+  };
 
   int buf = 0, ent1, ent2 = -1, sl1 = 0, sl2 = 0;
   {
@@ -386,9 +400,7 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_packed_split_kernel(const fl
   __syncthreads();
   {   // layer 1 of the first chunk on its own
     const int mtc0 = (min(TP, R) + 31) >> 5;
-    for (int mt = 0; mt < mtc0; ++mt)
-#pragma unroll
-      for (int sl = 0; sl < 6; ++sl) l1_slice(sl, l1_src(0, mt, true), l1_dst(mt, true), P1);
+    l1_chunk(0, mtc0 * 32);
   }
   const int nt0 = (wave % L3::WN) * NTW;
   GN_PROBE_INIT();
@@ -418,16 +430,13 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_packed_split_kernel(const fl
     }
     GN_PROBE(0);
     if constexpr (!RIDE) {
-      if (c > 0)
-        for (int mt = 0; mt < mtc; ++mt)
-#pragma unroll
-          for (int sl = 0; sl < 6; ++sl) l1_slice(sl, l1_src(buf, mt, true), l1_dst(mt, true), P1);
+      if (c > 0) l1_chunk(buf, mtc * 32);
     }
     GN_PROBE(1);
     __syncthreads();                   // layer 1 of this chunk (done under the previous chunk's layer 3) is published
     GN_PROBE(2);
     StoreSplit e2{bufY2, sp_stride(C2), P2, lane};
-    run_layer_split_t_pipe<TP, C1, C2>(w2, b2t, bufY1, P1, wave, lane, e2, mtc);
+    run_layer_split_t_pipe<TP, C1, C2, NWV>(w2, b2t, bufY1, P1, wave, lane, e2, mtc);
     GN_PROBE(3);
     if (has_next) put(buf ^ 1, c + 1, ent1, sl1, w1);     // published by the barrier below
     GN_PROBE(7);
@@ -504,11 +513,11 @@ __global__ __launch_bounds__(MLP_THREADS) void crop_packed_split_kernel(const fl
       __bf16 *l1d_ = l1_dst((MTI), l1a_);                                                                                \
       auto hook_ = [&](int kb) { if (kb < 6) l1_slice(kb, l1s_, l1d_, l1a_ ? P1 : 64 * 8); };                            \
       if constexpr (RIDE) {                                                                                              \
-        if (PEND) split_n_unit<1, C2, C3, ND>(w3, b3, xr(MTI), P2, DST, PRV, pool, gAc + ((MTI) - 1) * 32 * 4, pool, gAc, hook_); \
-        else split_n_unit<0, C2, C3, ND>(w3, b3, xr(MTI), P2, DST, DST, pool, gAc, pool, gAc, hook_);                     \
+        if (PEND) split_n_unit<1, C2, C3, ND, NWV>(w3, b3, xr(MTI), P2, DST, PRV, pool, gAc + ((MTI) - 1) * 32 * 4, pool, gAc, hook_); \
+        else split_n_unit<0, C2, C3, ND, NWV>(w3, b3, xr(MTI), P2, DST, DST, pool, gAc, pool, gAc, hook_);                     \
       } else {                                                                                                           \
-        if (PEND) split_n_unit<1, C2, C3, ND>(w3, b3, xr(MTI), P2, DST, PRV, pool, gAc + ((MTI) - 1) * 32 * 4, pool, gAc); \
-        else split_n_unit<0, C2, C3, ND>(w3, b3, xr(MTI), P2, DST, DST, pool, gAc, pool, gAc);                            \
+        if (PEND) split_n_unit<1, C2, C3, ND, NWV>(w3, b3, xr(MTI), P2, DST, PRV, pool, gAc + ((MTI) - 1) * 32 * 4, pool, gAc); \
+        else split_n_unit<0, C2, C3, ND, NWV>(w3, b3, xr(MTI), P2, DST, DST, pool, gAc, pool, gAc);                       \
       }                                                                                                                  \
     } while (0)
     GN_PROBE(14);
@@ -956,7 +965,17 @@ extern "C" int gn_crop_unique_mlp_pool_split(const float *xyz, const float *seed
       hipLaunchKernelGGL(k, dim3((nseeds + spb - 1) / spb), dim3(MLP_THREADS), lds_packed, as_stream(stream), xyz, n, seed_xyz,
                          rot, uidx, ucount, m, nseeds, spb, W, out);
     };
-    if (ride) go(crop_packed_split_kernel<64, 128, 256, 4, 256, TP, true>);
+    // GN_CROP_WAVES=8: the 8-wave form -- two waves per SIMD, every wave ONE n-tile of layer 3 and one of layer 2 resident
+    // (144 of its 256 registers), one wave's epilogues / pooling / staging under its SIMD partner's MFMAs
+    const char *we = getenv("GN_CROP_WAVES");
+    const int waves = we ? atoi(we) : 4;
+    auto go8 = [&](auto k) {
+      if ((rc = set_lds_attr(k, lds_packed, "crop_unique_mlp_pool_split"))) return;
+      hipLaunchKernelGGL(k, dim3((nseeds + spb - 1) / spb), dim3(512), lds_packed, as_stream(stream), xyz, n, seed_xyz,
+                         rot, uidx, ucount, m, nseeds, spb, W, out);
+    };
+    if (waves == 8) go8(crop_packed_split_kernel<64, 128, 256, 4, 256, TP, false, 8>);
+    else if (ride) go(crop_packed_split_kernel<64, 128, 256, 4, 256, TP, true>);
     else go(crop_packed_split_kernel<64, 128, 256, 4, 256, TP, false>);
     if (rc) return rc;
   } else if (pipe == 0) launch(crop_unique_split_kernel<64, 128, 256, 4, 256, TP, 0>);

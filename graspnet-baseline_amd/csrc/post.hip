@@ -129,44 +129,61 @@ __global__ __launch_bounds__(256) void voxel_insert_kernel(const float *__restri
 }
 
 // one workgroup per cloud: voxels ranked by their lowest member index (a prefix count of the leader flags) and, in the
-// same pass, the member-list offsets in that order (a prefix sum of the leaders' member counts)
+// same pass, the member-list offsets in that order (a prefix sum of the leaders' member counts).  Every wave owns one
+// contiguous run of the cloud: pass 1 adds up its leaders and their counts (all loads of a run in flight together, no
+// barrier), ONE barrier publishes the 16 totals, pass 2 walks the run again handing out ranks (ballot + mbcnt) and offsets
+// (a shuffle scan) behind the wave's base.  (The first form scanned 1024 points per step with three barriers each: 57 us.)
 __global__ __launch_bounds__(1024) void voxel_rank_kernel(const int32_t *__restrict__ pslot, const unsigned *__restrict__ first,
                                                           const int *__restrict__ cnt, int n, unsigned nslots,
                                                           int32_t *__restrict__ srank, int32_t *__restrict__ off,
                                                           int32_t *__restrict__ out_counts) {
   __shared__ int s_f[16], s_c[16];
-  __shared__ int s_cf, s_cc;
   const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   pslot += (size_t)b * n;
   first += (size_t)b * nslots; cnt += (size_t)b * nslots; srank += (size_t)b * nslots;
   off += (size_t)b * (n + 1);
-  if (t == 0) { s_cf = 0; s_cc = 0; }
+  const int run = ((n + 16 * 64 - 1) / (16 * 64)) * 64;      // points per wave, a multiple of 64
+  const int lo = wave * run, hi = min(n, lo + run);
+  auto look = [&](int i, bool &leader, int &c) {
+    const int slot = i < hi ? pslot[i] : -1;
+    leader = slot >= 0 && first[slot] == (unsigned)i;
+    c = leader ? cnt[slot] : 0;
+    return slot;
+  };
+  int facc = 0, cacc = 0;
+  for (int i = lo + lane; i < hi; i += 64) {
+    bool leader; int c;
+    look(i, leader, c);
+    facc += leader ? 1 : 0;
+    cacc += c;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { facc += __shfl_xor(facc, o); cacc += __shfl_xor(cacc, o); }
+  if (lane == 0) { s_f[wave] = facc; s_c[wave] = cacc; }
   __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + t;
-    const int slot = i < n ? pslot[i] : -1;
-    const bool leader = slot >= 0 && first[slot] == (unsigned)i;
-    const int f = leader ? 1 : 0, c = leader ? cnt[slot] : 0;
-    int inf = f, inc = c;
+  int rf = 0, rc = 0, nv = 0, total = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) { rf += s_f[w]; rc += s_c[w]; }
+    nv += s_f[w]; total += s_c[w];
+  }
+  for (int i0 = lo; i0 < hi; i0 += 64) {
+    bool leader; int c;
+    const int slot = look(i0 + lane, leader, c);
+    const unsigned long long m = __ballot(leader);
+    int incl = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      const int uf = __shfl_up(inf, o), uc = __shfl_up(inc, o);
-      if (lane >= o) { inf += uf; inc += uc; }
+      const int u = __shfl_up(incl, o);
+      if (lane >= o) incl += u;
     }
-    if (lane == 63) { s_f[wave] = inf; s_c[wave] = inc; }
-    __syncthreads();
-    int wf = s_cf, wc = s_cc;
-    for (int w = 0; w < wave; ++w) { wf += s_f[w]; wc += s_c[w]; }
     if (leader) {
-      const int pos = wf + inf - 1;
+      const int pos = rf + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
       srank[slot] = pos;
-      off[pos] = wc + inc - c;
+      off[pos] = rc + incl - c;
     }
-    __syncthreads();
-    if (t == 1023) { s_cf = wf + inf; s_cc = wc + inc; }
-    __syncthreads();
+    rf += __popcll(m);
+    rc += __shfl(incl, 63);
   }
-  const int nv = s_cf, total = s_cc;
   for (int a = nv + t; a <= n; a += 1024) off[a] = total;
   if (t == 0) out_counts[b] = nv;
 }

@@ -123,6 +123,19 @@ def test_crop_packed_rows_equal_padded_tiles(ref, net, monkeypatch):
         res.append(v)
     # (with m = 1000 the kernel reads seed / rot / uidx rows 0..999 of the same buffers: row stride is per seed)
     assert not torch.isnan(res[0]).any() and torch.equal(res[0], res[1])
+    # the 8-wave form (two waves per SIMD, one n-tile of each layer resident per wave): the same rows through the same MFMAs
+    # in the same k order -> the same bits, on the full batch, the ragged seed count and the 3-seeds-per-workgroup case
+    monkeypatch.setenv("GN_CROP_PACKED", "1")
+    for waves in ("8", "4"):
+        monkeypatch.setenv("GN_CROP_WAVES", waves)
+        for (bb, mm, want) in ((B, M, outs["1"]), (1, 1000, res[0])):
+            v = torch.full((bb, mm * 4, 256), float("nan"), device="cuda")
+            L.check(lib.gn_crop_unique_mlp_pool_split(xyz.data_ptr(), seed.data_ptr(), rot.data_ptr(), uidx.data_ptr(),
+                                                      ucount.data_ptr(), bb, N, mm, 4, 64, mlp, pks.wptr, pks.bptr, v.data_ptr(), st),
+                    "crop split waves=" + waves)
+            torch.cuda.synchronize()
+            assert torch.equal(v, want), (waves, bb, mm)
+    monkeypatch.delenv("GN_CROP_WAVES")
     # 2047 seeds as ONE cloud: 3 seeds per workgroup, the last workgroup holds a single seed
     res = []
     for mode in ("1", "0"):

@@ -128,34 +128,42 @@ __global__ __launch_bounds__(256) void voxel_insert_kernel(const float *__restri
   pslot[i] = -1;
 }
 
+// one thread per point: lc[i] = its voxel's member count if the point is the voxel's lowest member (its "leader"), else 0.
+// Wide on purpose: the two dependent random reads (slot -> first / cnt) are what the ranking pass below must NOT do on its
+// one workgroup per cloud (done there they were 40 serial L2 round trips per wave: 57-70 us).
+__global__ __launch_bounds__(256) void voxel_leader_kernel(const int32_t *__restrict__ pslot, const unsigned *__restrict__ first,
+                                                           const int *__restrict__ cnt, int n, unsigned nslots,
+                                                           int32_t *__restrict__ lc) {
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (i >= n) return;
+  const int slot = pslot[(size_t)b * n + i];
+  int v = 0;
+  if (slot >= 0 && first[(size_t)b * nslots + slot] == (unsigned)i) v = cnt[(size_t)b * nslots + slot];
+  lc[(size_t)b * n + i] = v;
+}
+
 // one workgroup per cloud: voxels ranked by their lowest member index (a prefix count of the leader flags) and, in the
-// same pass, the member-list offsets in that order (a prefix sum of the leaders' member counts).  Every wave owns one
-// contiguous run of the cloud: pass 1 adds up its leaders and their counts (all loads of a run in flight together, no
-// barrier), ONE barrier publishes the 16 totals, pass 2 walks the run again handing out ranks (ballot + mbcnt) and offsets
-// (a shuffle scan) behind the wave's base.  (The first form scanned 1024 points per step with three barriers each: 57 us.)
-__global__ __launch_bounds__(1024) void voxel_rank_kernel(const int32_t *__restrict__ pslot, const unsigned *__restrict__ first,
-                                                          const int *__restrict__ cnt, int n, unsigned nslots,
-                                                          int32_t *__restrict__ srank, int32_t *__restrict__ off,
-                                                          int32_t *__restrict__ out_counts) {
+// same pass, the member-list offsets in that order (a prefix sum of the leaders' member counts), both from the lc[] stream.
+// Every wave owns one contiguous run of the cloud: pass 1 adds up its leaders and their counts, ONE barrier publishes the
+// 16 totals, pass 2 walks the run again handing out ranks (ballot + mbcnt) and offsets (a shuffle scan) behind the wave's base.
+__global__ __launch_bounds__(1024) void voxel_rank_kernel(const int32_t *__restrict__ pslot, const int32_t *__restrict__ lc,
+                                                          int n, unsigned nslots, int32_t *__restrict__ srank,
+                                                          int32_t *__restrict__ off, int32_t *__restrict__ out_counts) {
   __shared__ int s_f[16], s_c[16];
   const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   pslot += (size_t)b * n;
-  first += (size_t)b * nslots; cnt += (size_t)b * nslots; srank += (size_t)b * nslots;
+  lc += (size_t)b * n;
+  srank += (size_t)b * nslots;
   off += (size_t)b * (n + 1);
   const int run = ((n + 16 * 64 - 1) / (16 * 64)) * 64;      // points per wave, a multiple of 64
   const int lo = wave * run, hi = min(n, lo + run);
-  auto look = [&](int i, bool &leader, int &c) {
-    const int slot = i < hi ? pslot[i] : -1;
-    leader = slot >= 0 && first[slot] == (unsigned)i;
-    c = leader ? cnt[slot] : 0;
-    return slot;
-  };
   int facc = 0, cacc = 0;
-  for (int i = lo + lane; i < hi; i += 64) {
-    bool leader; int c;
-    look(i, leader, c);
-    facc += leader ? 1 : 0;
-    cacc += c;
+  for (int i0 = lo; i0 < hi; i0 += 256) {                    // four coalesced loads in flight per lane
+    int c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = i0 + u * 64 + lane; c[u] = i < hi ? lc[i] : 0; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { facc += c[u] > 0 ? 1 : 0; cacc += c[u]; }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { facc += __shfl_xor(facc, o); cacc += __shfl_xor(cacc, o); }
@@ -166,23 +174,32 @@ __global__ __launch_bounds__(1024) void voxel_rank_kernel(const int32_t *__restr
     if (w < wave) { rf += s_f[w]; rc += s_c[w]; }
     nv += s_f[w]; total += s_c[w];
   }
-  for (int i0 = lo; i0 < hi; i0 += 64) {
-    bool leader; int c;
-    const int slot = look(i0 + lane, leader, c);
-    const unsigned long long m = __ballot(leader);
-    int incl = c;
+  for (int i0 = lo; i0 < hi; i0 += 256) {
+    int c[4], sl[4];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int u = __shfl_up(incl, o);
-      if (lane >= o) incl += u;
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 64 + lane;
+      c[u] = i < hi ? lc[i] : 0;
+      sl[u] = i < hi ? pslot[i] : -1;
     }
-    if (leader) {
-      const int pos = rf + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-      srank[slot] = pos;
-      off[pos] = rc + incl - c;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool leader = c[u] > 0;
+      const unsigned long long m = __ballot(leader);
+      int incl = c[u];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+      }
+      if (leader) {
+        const int pos = rf + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        srank[sl[u]] = pos;
+        off[pos] = rc + incl - c[u];
+      }
+      rf += __popcll(m);
+      rc += __shfl(incl, 63);
     }
-    rf += __popcll(m);
-    rc += __shfl(incl, 63);
   }
   for (int a = nv + t; a <= n; a += 1024) off[a] = total;
   if (t == 0) out_counts[b] = nv;
@@ -615,7 +632,9 @@ extern "C" int gn_voxel_down_sample_batched(const float *points, const int32_t *
   hipLaunchKernelGGL(voxel_minbound_kernel, dim3(b), dim3(1024), 0, s, points, n_valid, n, w.hdr, status);
   hipLaunchKernelGGL(voxel_insert_kernel, gp, dim3(256), 0, s, points, n_valid, n, voxel_size, w.hdr, w.keys, w.first, w.cnt,
                      w.pslot, slots - 1, status);
-  hipLaunchKernelGGL(voxel_rank_kernel, dim3(b), dim3(1024), 0, s, w.pslot, w.first, w.cnt, n, slots, w.srank, w.off, out_counts);
+  // (lc lives in w.vidx until the fill pass overwrites it with the points' voxel ranks)
+  hipLaunchKernelGGL(voxel_leader_kernel, gp, dim3(256), 0, s, w.pslot, w.first, w.cnt, n, slots, w.vidx);
+  hipLaunchKernelGGL(voxel_rank_kernel, dim3(b), dim3(1024), 0, s, w.pslot, w.vidx, n, slots, w.srank, w.off, out_counts);
   hipLaunchKernelGGL(voxel_fill_kernel, gp, dim3(256), 0, s, w.pslot, w.srank, w.off, w.cursor, n, slots, w.vidx, w.list);
   GN_CHECK_LAUNCH("voxel_down_sample");
   if (int rc = seg_order(w.vidx, b, n, n, w.off, w.list, s)) return rc;

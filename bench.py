@@ -114,7 +114,7 @@ def cpu_baseline(n_points, reps1, reps8):
 
 def pmc_file():
     """The committed PMC passes of the bench command (HBM bytes per launch); newest round first."""
-    for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1g_pmc_traffic.json"):
+    for name in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1g_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
@@ -181,9 +181,17 @@ def op_rooflines(dev, reps=20, n_points=20000):
         r.update(extra)
         out[name] = r
 
+    # every drop-in query bins its cloud (round 3) unless the cloud was binned by the previous query on the same stream
+    # (round 4: graspnet_amd/pointnet2_ext.py _grid_for; the reference model queries one cloud five times per forward):
+    # "_cold" = grid build + query (GN_GRID_CACHE=0: what the first query on a cloud costs), plain = the query on the kept grid
+    os.environ["GN_GRID_CACHE"] = "0"
     t = timed(lambda: E.ball_query(ctr, xyz, 0.04, 64))
-    rec("ball_query_sa1", 788864 * 8, t, "latency / VALU issue (grid cells then a sorted 64-lane register), HBM-trivial",
+    rec("ball_query_sa1_cold", 788864 * 8, t, "latency / VALU issue: grid build (one workgroup per cloud) + query, HBM-trivial",
         tests_per_s_brute_force_equivalent=8 * 2048 * 20000 / t)
+    os.environ["GN_GRID_CACHE"] = "1"
+    t = timed(lambda: E.ball_query(ctr, xyz, 0.04, 64))
+    rec("ball_query_sa1", 788864 * 8, t, "latency / VALU issue (grid cells then a sorted 64-lane register), HBM-trivial; the cloud's grid "
+        "is reused from the previous query on it", tests_per_s_brute_force_equivalent=8 * 2048 * 20000 / t)
     feat = torch.rand(8, 128, 2048, device=dev)
     idx = torch.randint(0, 2048, (8, 1024, 32), device=dev, dtype=torch.int32)
     t = timed(lambda: E.group_points(feat, idx))
@@ -194,8 +202,13 @@ def op_rooflines(dev, reps=20, n_points=20000):
     rec("group_points_sa1", 2337152 * 8, t, "hbm (write)")
     rot = torch.eye(3, device=dev).reshape(1, 1, 9).repeat(8, 1024, 1).contiguous()
     seeds = xyz[:, :1024].contiguous()
+    os.environ["GN_GRID_CACHE"] = "0"
     t = timed(lambda: E.cylinder_query(seeds, xyz, rot, 0.05, -0.02, 0.04, 64))
-    rec("cylinder_query", 551296 * 8, t, "latency / VALU issue, HBM-trivial")
+    rec("cylinder_query_cold", 551296 * 8, t, "latency / VALU issue: grid build + query, HBM-trivial")
+    os.environ["GN_GRID_CACHE"] = "1"
+    t = timed(lambda: E.cylinder_query(seeds, xyz, rot, 0.05, -0.02, 0.04, 64))
+    rec("cylinder_query", 551296 * 8, t, "latency / VALU issue, HBM-trivial; grid reused (CloudCrop's four queries bin the cloud once)")
+    E.clear_grid_cache()
     return out
 
 

@@ -104,3 +104,32 @@ def test_argument_checks_answer_before_any_launch():
     assert lib.gn_ball_query_grid(addr, addr, 1, 5000, 8, 0.04, 65, addr, None) == -1 and b"nsample <= 64" in lib.gn_last_error()
     assert lib.gn_furthest_point_sampling(None, 1, 100, 10, None, addr, None, None, None, None) == -1
     assert lib.gn_fps_workspace_bytes(8, 50000) >= 8 * 65536 * 20 and lib.gn_fps_workspace_bytes(8, 2048) == 0
+
+
+def test_argument_checks_of_the_round4_entry_points():
+    """the batched front end / post-processing entry points answer a bad call before any launch (no GPU needed)"""
+    import ctypes
+    from graspnet_amd import _lib
+    lib = _lib.lib()
+    dummy = (ctypes.c_char * 4096)()
+    addr = (ctypes.addressof(dummy) + 255) & ~255
+    # voxel down-sample: null output / misaligned workspace / non-positive voxel size
+    assert lib.gn_voxel_down_sample_batched(addr, None, 2, 100, 0.01, addr, None, addr, addr, None) == -1
+    assert b"null pointer" in lib.gn_last_error()
+    assert lib.gn_voxel_down_sample_batched(addr, None, 2, 100, 0.01, addr + 8, addr, addr, addr, None) == -1
+    assert b"256-byte aligned" in lib.gn_last_error()
+    assert lib.gn_voxel_down_sample_batched(addr, None, 2, 100, 0.0, addr, addr, addr, addr, None) == -1
+    assert lib.gn_voxel_batched_workspace_bytes(8, 20000) > 8 * 65536 * 12 and lib.gn_voxel_batched_workspace_bytes(0, 5) == 0
+    assert lib.gn_voxel_workspace_bytes(20000) == 256 + lib.gn_voxel_batched_workspace_bytes(1, 20000)
+    # collision detect: null scene / too many scene points for the queue's packed index
+    assert lib.gn_collision_detect_batched(None, 100, None, addr, None, 1, 8, 0.05, 0.01, 0.01, 0.01, 0.01, 0.06, addr, None, None,
+                                           None) == -1 and b"null pointer" in lib.gn_last_error()
+    assert lib.gn_collision_detect_batched(addr, 1 << 28, None, addr, None, 1, 8, 0.05, 0.01, 0.01, 0.01, 0.01, 0.06, addr, None,
+                                           None, None) == -1 and b"2^28" in lib.gn_last_error()
+    # front end: zero depth factor, neither positions nor random words
+    assert lib.gn_depth_valid_compact(addr, None, 1, 4, 4, 0.0, 0.0, 1.0, addr, addr, addr, None) == -1
+    assert lib.gn_depth_sample_cloud(addr, 1, 4, 4, 1.0, 1.0, 0.0, 0.0, 1000.0, addr, addr, None, None, 8, addr, None, None) == -1
+    assert b"positions or random words" in lib.gn_last_error()
+    assert lib.gn_frontend_workspace_bytes(2, 720, 1280) == 2 * (900 + 1) * 4
+    # knn: k > 8 needs the scratch plane
+    assert lib.gn_knn(addr, addr, 1, 3, 10, 10, 9, addr, None, None) == -1 and b"scratch" in lib.gn_last_error()

@@ -195,6 +195,38 @@ def test_collision_detect_batched_equals_one_detector_per_scene(state_dict):
     assert len({int(cm[b].sum()) for b in range(B)}) > 1          # the scenes really differ
 
 
+def test_post_processing_edge_cases():
+    """empty scenes, scenes without grasps, clouds that are all padding: defined outputs, no faults"""
+    from graspnet_amd import postprocess as P
+    from oracle import post_oracle as PO
+    rng = np.random.default_rng(8)
+    B, n, M = 3, 3000, 40
+    clouds = torch.from_numpy(rng.uniform(-0.2, 0.2, size=(B, n, 3)).astype(np.float32)).cuda()
+    clouds[..., 2] += 0.5
+    nv = torch.tensor([n, 0, 7], dtype=torch.int32, device="cuda")           # cloud 1: every point is padding
+    g = torch.zeros((B, M, 17), device="cuda")
+    g[:, :, 0] = torch.rand(B, M, device="cuda")
+    g[:, :, 1:4] = torch.tensor([0.08, 0.02, 0.02], device="cuda")
+    g[:, :, 4:13] = torch.eye(3, device="cuda").reshape(9)
+    g[:, :, 13:16] = clouds[:, :M]
+    counts = torch.tensor([M, M, 0], dtype=torch.int32, device="cuda")       # scene 2: no grasps
+    det = P.BatchedCollisionDetector(clouds, voxel_size=0.01, n_valid=nv)
+    nsc = det.scene_counts.cpu().tolist()
+    assert nsc[1] == 0 and 0 < nsc[2] <= 7 and nsc[0] == len(PO.voxel_down_sample_ordered(clouds[0].cpu().numpy(), 0.01))
+    cm, em, io = det.detect_padded(g, counts, approach_dist=0.05, collision_thresh=0.01, return_empty_grasp=True, return_ious=True)
+    assert not cm[1].any() and em[1].all() and not io[1].any()                # no scene points: nothing collides, every grasp is "empty"
+    assert not cm[2].any() and not em[2].any() and not io[2].any()            # no grasps: padding rows only
+    wcm, wem, _ = PO.collision_detect(det.scene_points[0, :nsc[0]].cpu().numpy(), g[0].cpu().numpy(), approach_dist=0.05,
+                                      collision_thresh=0.01, voxel_size=0.01)
+    assert np.array_equal(cm[0].cpu().numpy(), wcm) and np.array_equal(em[0].cpu().numpy(), wem) and wcm.any()
+    rows, kept, _ = P.grasp_pipeline(clouds, g, counts, n_valid=nv)
+    k = kept.cpu().tolist()
+    assert k[2] == 0 and not rows[2].any() and 0 < k[1] <= M and k[0] <= M
+    # one point, one voxel; and a batch of one
+    o, c, st = P.voxel_down_sample_batched(torch.tensor([[[0.1, 0.2, 0.3]]], device="cuda"), 0.005)
+    assert c.cpu().tolist() == [1] and st.cpu().tolist() == [0] and np.allclose(o[0, 0].cpu().numpy(), [0.1, 0.2, 0.3])
+
+
 def test_collision_detect_batched_vs_reference_detect_golden(golden_dir):
     """tests/golden/collision_ref.npz holds the outputs of the REFERENCE's ModelFreeCollisionDetector.detect
     (utils/collision_detector.py:69-129, run by tests/golden/make_golden_collision.py in the build container) for three caller

@@ -374,6 +374,9 @@ static __device__ unsigned long long gn_phase_probe[8 * 16];   // one table per 
 #define GN_PROBE_INIT() unsigned long long pt_[16] = {}; unsigned long long pl_ = __builtin_amdgcn_s_memtime()
 #define GN_PROBE(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pt_[i] += n_ - pl_; pl_ = n_; } while (0)
 #define GN_PROBE_COUNT(i, v) pt_[i] += (unsigned long long)(v)
+// a finer mark INSIDE a phase: slot i gets the time since the previous mark of either kind, and the enclosing phase's own
+// GN_PROBE later gets only what is left (sub-marks are taken out of it)
+#define GN_PROBE_SUB(i) GN_PROBE(i)
 #define GN_PROBE_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&gn_phase_probe[(threadIdx.x >> 6) * 16 + i_], pt_[i_]); } while (0)
 #define GN_PROBE_READER(fn)                                                                                         \
   extern "C" int fn(unsigned long long *host, int reset) {                                                          \
@@ -389,6 +392,7 @@ static __device__ unsigned long long gn_phase_probe[8 * 16];   // one table per 
 #define GN_PROBE_INIT()
 #define GN_PROBE(i)
 #define GN_PROBE_COUNT(i, v)
+#define GN_PROBE_SUB(i)
 #define GN_PROBE_FLUSH()
 #endif
 

@@ -557,37 +557,33 @@ __global__ __launch_bounds__(NWV * 64) void crop_packed_split_kernel(const float
   GN_PROBE_FLUSH();
 }
 
-// ---- CloudCrop on packed rows, EIGHT waves: two per SIMD, the two wave groups HALF A CHUNK APART -------------------------
+// ---- CloudCrop on packed rows, EIGHT waves: two per SIMD, the two wave groups on DIFFERENT JOBS -------------------------
 // (round-3 VERDICT item 4)  The 4-wave kernel above runs ONE wave per SIMD (496 registers: 240 of
 // resident weights) and its phases are serial inside that wave: the matrix core idles through every epilogue, pooling
 // tail, staging step and barrier (MFMA-busy 44 %).  Two waves per SIMD only help if, whenever one of them is NOT issuing
 // MFMAs, the other one is -- eight waves walking the same phases between the same barriers do not (measured: 0.33-0.35 ms
-// against 0.36; profiles/README.md).  So the two groups are given different jobs and run half a slot apart:
-//   group A (waves 0-3: one per SIMD)  first half : layer 3 of chunk c, n-tiles 0-3
-//                                      second half: layer 1 of chunk c+2 (vector ALUs) + staging of chunk c+3
-//   group B (waves 4-7)                first half : layer 2 of chunk c+1 (all four n-tiles, all M tiles)
-//                                      second half: layer 3 of chunk c, n-tiles 4-7
-// with one workgroup barrier between the halves and one between slots.  In the first half the matrix core is fed by A's
-// layer 3 and B's layer 2 together, in the second by B's layer 3 while A does everything that needs no MFMA.
+// against 0.36; profiles/README.md).  So the two groups are given different jobs inside a slot of 32 rows (one M tile):
+//   group A (waves 0-3: one per SIMD):  layer 3 of chunk c (n-tiles 0-3)  ->  layer 1 of chunk c+2  ->  staging of chunk c+3
+//   group B (waves 4-7)              :  layer 2 of chunk c+1 (its four n-tiles)  ->  layer 3 of chunk c (n-tiles 4-7)
+// and ONE workgroup barrier per slot: Y1 (layer 1's output), Y2 (layer 2's) and the staged coordinates are all
+// double-buffered, so every hazard lies between slots, never inside one, and the groups drift freely within a slot.
 //   * every wave keeps ONE of layer 3's eight n-tiles resident (96 AGPRs of its 256 registers); layer 2's fragments (a
 //     group-B wave's n-tile: 12 KB) are streamed from L2, requested in front of the slot barrier they are used behind;
-//   * Y2 (layer 2's output) is double-buffered -- layer 2 of chunk c+1 is written while layer 3 of chunk c is read -- which
-//     the LDS only holds for 64-row chunks (2 x 52 KB + Y1 28 KB + coordinates / gate rings: 149 KB);
-//   * a tile's masked pooling rides under the MFMAs of the wave's next tile as before; the chunk's last tile is pooled on
-//     its own, under the OTHER group's MFMAs.
+//   * a chunk is ONE 32-row tile -- the double buffers of a 64-row chunk need 176 KB of LDS -- so nothing rides inside a
+//     wave: a tile's pooling, close-outs and epilogues run under the OTHER wave's MFMAs.
 // Rows, k order, products and max() are those of the 4-wave kernel: bit-identical output (tests/test_split_gpu.py).
 template <int C1, int C2, int C3, int ND, int CAP>
 __global__ __launch_bounds__(512) void crop8_split_kernel(const float *__restrict__ xyz, int n, const float *__restrict__ seed,
                                                           const float *__restrict__ rot, const int32_t *__restrict__ uidx,
                                                           const int32_t *__restrict__ ucount, int m, int nseeds, int spb,
                                                           SplitWeights W, float *__restrict__ out) {
-  constexpr int TP = 64, NWV = 8, CIN0 = 8, XS0 = lds_stride(CIN0), MT = TP / 32, RING = 4;
+  constexpr int TP = 32, NWV = 8, CIN0 = 8, XS0 = lds_stride(CIN0), RING = 4;
   static_assert(C1 == 64 && C2 == 128 && C3 == 256, "written for CloudCrop's 64-128-256 layers");
   constexpr int P2 = TP * sp_stride(C2), P1 = TP * sp_stride(C1);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __bf16 *bufY2 = reinterpret_cast<__bf16 *>(smem_raw);            // 2 x 3 x [TP][C2+8]   (chunk & 1)
-  __bf16 *bufY1 = bufY2 + 2 * 3 * P2;                              // 3 x [TP][C1+8]
-  float *bufX = reinterpret_cast<float *>(bufY1 + 3 * P1);         // 2 x [TP][12]: rotated coordinates (chunk & 1)
+  __bf16 *bufY1 = bufY2 + 2 * 3 * P2;                              // 2 x 3 x [TP][C1+8]   (chunk & 1)
+  float *bufX = reinterpret_cast<float *>(bufY1 + 2 * 3 * P1);     // 2 x [TP][12]: rotated coordinates (chunk & 1)
   float *bufGA = bufX + 2 * TP * XS0;                              // RING x [TP][4] gates towards the tile's first seed
   float *bufGB = bufGA + RING * TP * 4;                            // RING x [TP][4] ... towards its second seed
   int *bufS = reinterpret_cast<int *>(bufGB + RING * TP * 4);      // RING x [TP] seed slot | depth mask << 8 (-1: no row)
@@ -595,13 +591,12 @@ __global__ __launch_bounds__(512) void crop8_split_kernel(const float *__restric
   float *bufB2 = bufW1 + C1 * 4;                                   // [C2] layer-2 bias
   __shared__ int s_off[kCropMaxSpb + 1];
   __shared__ float s_seed[kCropMaxSpb][12];                        // per seed slot: centre (3) + rotation (9)
-  // the wave index as a SCALAR: the group branches below must be uniform branches -- as divergent ones the compiler lays
-  // both sides out one after the other and keeps group B's streamed weights alive across group A's layer 3 (83 spills)
+  // the wave index as a SCALAR: the group branches below must be uniform branches
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool groupA = wave < 4;                                    // SIMD s holds waves s (group A) and s + 4 (group B)
 
-  using L2 = LayerWS<C1, C2, 4>;        // the four group-B waves: n-tile wave - 4, every M tile
-  using L3 = LayerWS<C2, C3, NWV>;      // n-tile wave, every M tile
+  using L2 = LayerWS<C1, C2, 4>;        // the four group-B waves: n-tile wave - 4
+  using L3 = LayerWS<C2, C3, NWV>;      // n-tile wave
   static_assert(L2::NTW == 1 && L3::NTW == 1 && L2::KB == 4 && L3::KB == 8 && L2::WM == 1 && L3::WM == 1, "tiling");
   L3 w3;
   w3.template load<true>(W.w3, wave, lane);
@@ -642,7 +637,7 @@ __global__ __launch_bounds__(512) void crop8_split_kernel(const float *__restric
     for (int k = 1; k < kCropMaxSpb; ++k) sl += (p >= s_off[k]) ? 1 : 0;
     return sl;
   };
-  auto rows_of = [&](int c) { return min(TP, R - c * TP); };
+  GN_PROBE_INIT();
   // ---- staging (threads 0 .. TP-1, group A): row `tid` of a chunk
   const bool stager = tid < TP;
   auto load_e = [&](int c, int &slot) -> int {
@@ -674,7 +669,7 @@ __global__ __launch_bounds__(512) void crop8_split_kernel(const float *__restric
       f32x4 g;
 #pragma unroll
       for (int d = 0; d < ND; ++d) g[d] = ((mk >> d) & 1u) ? 0.f : -INFINITY;
-      const int a_tile = slot_of(c * TP + (tid & ~31));
+      const int a_tile = slot_of(c * TP);
       if (slot == a_tile) ga = g;
       if (slot == a_tile + 1) gb = g;
       sv = slot | (int)(mk << 8) | ((c * TP + tid + 1 == s_off[slot + 1]) ? 0x10000 : 0);
@@ -686,88 +681,71 @@ __global__ __launch_bounds__(512) void crop8_split_kernel(const float *__restric
     *reinterpret_cast<f32x4 *>(bufGB + (c % RING) * TP * 4 + tid * 4) = gb;
     bufS[(c % RING) * TP + tid] = sv;
   };
-  // ---- layer 1 (K = 3, vector ALUs) by group A's 256 threads: one (row, 8 channels) item per thread and pass of 32 rows
+  // ---- layer 1 (K = 3, vector ALUs) by group A's 256 threads: one (row, 8 channels) item per thread, into Y1[c & 1]
   const float *l1w = bufW1 + (tid & 7) * 8 * 4;
   auto l1_chunk = [&](int c) {
-    const int nrows = ((rows_of(c) + 31) >> 5) * 32;
-    for (int r0 = 0; r0 < nrows; r0 += 32) {
-      const int row = r0 + (tid >> 3);
-      const f32x4 x = *reinterpret_cast<const f32x4 *>(bufX + (c & 1) * TP * XS0 + row * XS0);
-      float y[8];
+    const int row = tid >> 3;
+    const f32x4 x = *reinterpret_cast<const f32x4 *>(bufX + (c & 1) * TP * XS0 + row * XS0);
+    float y[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const f32x4 wv = *reinterpret_cast<const f32x4 *>(l1w + j * 4);
-        y[j] = __builtin_fmaf(x[2], wv[2], __builtin_fmaf(x[1], wv[1], __builtin_fmaf(x[0], wv[0], wv[3])));
-      }
-      u32x2 h0, m0, l0, h1, m1, l1;
-      split4<true>(y[0], y[1], y[2], y[3], h0, m0, l0);
-      split4<true>(y[4], y[5], y[6], y[7], h1, m1, l1);
-      using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-      __bf16 *dst = bufY1 + row * sp_stride(C1) + (tid & 7) * 8;
-      *reinterpret_cast<u32x4 *>(dst) = u32x4{h0[0], h0[1], h1[0], h1[1]};
-      *reinterpret_cast<u32x4 *>(dst + P1) = u32x4{m0[0], m0[1], m1[0], m1[1]};
-      *reinterpret_cast<u32x4 *>(dst + 2 * P1) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+    for (int j = 0; j < 8; ++j) {
+      const f32x4 wv = *reinterpret_cast<const f32x4 *>(l1w + j * 4);
+      y[j] = __builtin_fmaf(x[2], wv[2], __builtin_fmaf(x[1], wv[1], __builtin_fmaf(x[0], wv[0], wv[3])));
     }
+    u32x2 h0, m0, l0, h1, m1, l1;
+    split4<true>(y[0], y[1], y[2], y[3], h0, m0, l0);
+    split4<true>(y[4], y[5], y[6], y[7], h1, m1, l1);
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    __bf16 *dst = bufY1 + (c & 1) * 3 * P1 + row * sp_stride(C1) + (tid & 7) * 8;
+    *reinterpret_cast<u32x4 *>(dst) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+    *reinterpret_cast<u32x4 *>(dst + P1) = u32x4{m0[0], m0[1], m1[0], m1[1]};
+    *reinterpret_cast<u32x4 *>(dst + 2 * P1) = u32x4{l0[0], l0[1], l1[0], l1[1]};
   };
-  // ---- layer 2 of chunk c (group B: T orientation, rows = channels of n-tile wn2), every M tile, into Y2[c & 1]
+  // ---- layer 2 of chunk c (group B: T orientation, rows = channels of n-tile wn2): Y1[c & 1] -> Y2[c & 1]
   auto layer2 = [&](int c, const bf16x8 (&w2h)[L2::KB], const bf16x8 (&w2m)[L2::KB], const bf16x8 (&w2l)[L2::KB]) {
-    const int mtc = (rows_of(c) + 31) >> 5;
-    for (int mt = 0; mt < mtc; ++mt) {
-      f32x16 acc;
+    f32x16 acc;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bufB2 + wn2 * 32 + 8 * g + 4 * (lane >> 5));
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bv = *reinterpret_cast<const f32x4 *>(bufB2 + wn2 * 32 + 8 * g + 4 * (lane >> 5));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[4 * g + j] = bv[j];
-      }
-      const __bf16 *xr = bufY1 + (mt * 32 + (lane & 31)) * sp_stride(C1) + 8 * (lane >> 5);
-      bf16x8 a[L2::KB][3];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) a[kb][p] = *reinterpret_cast<const bf16x8 *>(xr + p * P1 + kb * 16);
-#pragma unroll
-      for (int kb = 0; kb < L2::KB; ++kb) {     // mfma6<true>'s order: (x2,w0) (x1,w1) (x0,w2) (x1,w0) (x0,w1) (x0,w0)
-        if (kb + 2 < L2::KB) {
-#pragma unroll
-          for (int p = 0; p < 3; ++p) a[kb + 2][p] = *reinterpret_cast<const bf16x8 *>(xr + p * P1 + (kb + 2) * 16);
-        }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2h[kb], a[kb][2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2m[kb], a[kb][1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2l[kb], a[kb][0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2h[kb], a[kb][1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2m[kb], a[kb][0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2h[kb], a[kb][0], acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      StoreSplit e2{bufY2 + (c & 1) * 3 * P2, sp_stride(C2), P2, lane};
-      e2(mt, wn2, acc);
+      for (int j = 0; j < 4; ++j) acc[4 * g + j] = bv[j];
     }
+    const __bf16 *xr = bufY1 + (c & 1) * 3 * P1 + (lane & 31) * sp_stride(C1) + 8 * (lane >> 5);
+    bf16x8 a[L2::KB][3];
+#pragma unroll
+    for (int kb = 0; kb < L2::KB; ++kb)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[kb][p] = *reinterpret_cast<const bf16x8 *>(xr + p * P1 + kb * 16);
+#pragma unroll
+    for (int kb = 0; kb < L2::KB; ++kb) {       // mfma6<true>'s order: (x2,w0) (x1,w1) (x0,w2) (x1,w0) (x0,w1) (x0,w0)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2h[kb], a[kb][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2m[kb], a[kb][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2l[kb], a[kb][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2h[kb], a[kb][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2m[kb], a[kb][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2h[kb], a[kb][0], acc, 0, 0, 0);
+    }
+    GN_PROBE_SUB(11);                   // MFMAs of the unit (incl. the wait for its operands)
+    StoreSplit e2{bufY2 + (c & 1) * 3 * P2, sp_stride(C2), P2, lane};
+    e2(0, wn2, acc);
+    GN_PROBE_SUB(12);                   // relu + three-way split + stores
   };
   // ---- layer 3 + masked pooling of chunk c, this wave's n-tile (N orientation), from Y2[c & 1]
   auto layer3 = [&](int c) {
-    const int rows = rows_of(c);
-    const int mtc = (rows + 31) >> 5;
+    const int rows = min(TP, R - c * TP);
     const float *gAc = bufGA + (c % RING) * TP * 4 + (4 * (lane >> 5)) * 4;
     const float *gBc = bufGB + (c % RING) * TP * 4 + (4 * (lane >> 5)) * 4;
     const int *sch = bufS + (c % RING) * TP;
     const int p0 = c * TP;
-    int ta[MT], tz[MT];
-    bool tend[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      ta[mt] = tz[mt] = 0; tend[mt] = false;
-      if (mt < mtc) {
-        const int wa = __builtin_amdgcn_readfirstlane(sch[mt * 32]);
-        const int wz = __builtin_amdgcn_readfirstlane(sch[min(rows, mt * 32 + 32) - 1]);
-        ta[mt] = wa & 0xff; tz[mt] = wz & 0xff; tend[mt] = (wz & 0x10000) != 0;
-      }
-    }
+    const int wa = __builtin_amdgcn_readfirstlane(sch[0]);
+    const int wz = __builtin_amdgcn_readfirstlane(sch[rows - 1]);
+    const int ta = wa & 0xff, tz = wz & 0xff;
+    const bool tend = (wz & 0x10000) != 0;
     auto finish_seed = [&](int q) {
       pool.finish(out + (size_t)(s0 + q) * ND * C3, C3, wave);
       pool.reset();
     };
-    auto pool_lean = [&](const f32x16 &src, const float *gb) {      // a tile on its own, gates read a slice ahead
+    auto pool_lean = [&](const f32x16 &src, const float *gb) {      // gates read a slice ahead
       f32x4 g[2][2];
       auto gread = [&](int j) {
         const int r = 2 * j, rb = (r & 3) + 8 * (r >> 2);
@@ -783,56 +761,41 @@ __global__ __launch_bounds__(512) void crop8_split_kernel(const float *__restric
           pool.hold[d][0] = fmaxf(pool.hold[d][0], fmaxf(src[2 * j] + g[j & 1][0][d], src[2 * j + 1] + g[j & 1][1][d]));
       }
     };
-    auto close_tile = [&](const f32x16 (&src)[1], int mt) {
-      if (tz[mt] == ta[mt]) {
-        if (tend[mt]) finish_seed(ta[mt]);
-      } else {                                    // the first seed ends inside the tile, the second gets its own pass
-        finish_seed(ta[mt]);
-        pool_lean(src[0], gBc + mt * 32 * 4);
-        if (tend[mt]) finish_seed(tz[mt]);
+    const __bf16 *xr = bufY2 + (c & 1) * 3 * P2 + (lane & 31) * sp_stride(C2) + 8 * (lane >> 5);
+    f32x16 acc[1];
+    GN_PROBE_SUB(15);
+    split_n_unit<0, C2, C3, ND, NWV>(w3, b3, xr, P2, acc, acc, pool, gAc, pool, gAc);
+    GN_PROBE_SUB(13);                   // the tile's 48 MFMAs
+    if (tz <= ta + 1) {
+      pool_lean(acc[0], gAc);
+      if (tz == ta) {
+        if (tend) finish_seed(ta);
+      } else {                          // the first seed ends inside the tile, the second gets its own pass
+        finish_seed(ta);
+        pool_lean(acc[0], gBc);
+        if (tend) finish_seed(tz);
       }
-    };
-    auto pool_many = [&](const f32x16 (&src)[1], int mt) {   // three or more seeds in one tile: one pass per seed
-      for (int q = ta[mt]; q <= tz[mt]; ++q) {
+    } else {                            // three or more seeds in one tile: one pass per seed, gates from the slot words
+      for (int q = ta; q <= tz; ++q) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const int rw = mt * 32 + acc_row(2 * j, lane);
+          const int rw = acc_row(2 * j, lane);
           const int s0w = sch[rw], s1w = sch[rw + 1];
 #pragma unroll
           for (int d = 0; d < ND; ++d) {
             const float g0 = ((s0w & 0xff) == q && s0w >= 0 && ((s0w >> (8 + d)) & 1)) ? 0.f : -INFINITY;
             const float g1 = ((s1w & 0xff) == q && s1w >= 0 && ((s1w >> (8 + d)) & 1)) ? 0.f : -INFINITY;
-            pool.hold[d][0] = fmaxf(pool.hold[d][0], fmaxf(src[0][2 * j] + g0, src[0][2 * j + 1] + g1));
+            pool.hold[d][0] = fmaxf(pool.hold[d][0], fmaxf(acc[0][2 * j] + g0, acc[0][2 * j + 1] + g1));
           }
         }
-        if (q < tz[mt] || s_off[q + 1] <= p0 + mt * 32 + 32) finish_seed(q);
+        if (q < tz || s_off[q + 1] <= p0 + 32) finish_seed(q);
       }
-    };
-    const __bf16 *xbase = bufY2 + (c & 1) * 3 * P2 + (lane & 31) * sp_stride(C2) + 8 * (lane >> 5);
-    f32x16 accA[1], accB[1];
-    split_n_unit<0, C2, C3, ND, NWV>(w3, b3, xbase, P2, accA, accA, pool, gAc, pool, gAc);
-    const bool pend0 = tz[0] <= ta[0] + 1;
-    if (!pend0) pool_many(accA, 0);
-    if (mtc > 1) {
-      if (pend0) {
-        split_n_unit<1, C2, C3, ND, NWV>(w3, b3, xbase + 32 * sp_stride(C2), P2, accB, accA, pool, gAc, pool, gAc);
-        close_tile(accA, 0);
-      } else {
-        split_n_unit<0, C2, C3, ND, NWV>(w3, b3, xbase + 32 * sp_stride(C2), P2, accB, accB, pool, gAc, pool, gAc);
-      }
-      if (tz[1] <= ta[1] + 1) { pool_lean(accB[0], gAc + 32 * 4); close_tile(accB, 1); }
-      else pool_many(accB, 1);
-    } else if (pend0) {
-      pool_lean(accA[0], gAc);
-      close_tile(accA, 0);
     }
   };
 
-  // ---- prologue: chunk 0 staged; entries of chunk 1 requested
   // The two groups run SEPARATE loops with the same number of workgroup barriers (s_barrier counts arrivals, not program
   // counters): written as one loop with group branches inside, the register allocator kept group B's streamed layer-2
   // fragments alive across group A's layer 3 (80 spilled registers).
-  GN_PROBE_INIT();
   if (groupA) {
     int ent_n, sl_n = 0;        // entry / seed slot of this thread's row in the NEXT chunk to stage
     {
@@ -851,12 +814,10 @@ __global__ __launch_bounds__(512) void crop8_split_kernel(const float *__restric
         ent_nn = load_e(c + 4, sl_nn);
       }
       GN_PROBE(0);
-      __syncthreads();      // slot barrier: Y2[c&1] (layer 2 of c), Y1 (layer 1 of c+1), the staged rows of c+2 are published
+      __syncthreads();      // the slot barrier: Y2[c&1] (layer 2 of c), Y1[(c+1)&1] (layer 1 of c+1), the rows of c+2 are published
       GN_PROBE(1);
       if (c >= 0) layer3(c);
       GN_PROBE(2);
-      __syncthreads();      // half barrier: Y1 is free (layer 2 of c+1 has read it), Y2[(c+1)&1] is published
-      GN_PROBE(3);
       if (c + 2 < nchunks) l1_chunk(c + 2);
       GN_PROBE(4);
       if (c + 3 < nchunks) put(c + 3, ent_n, sl_n, wr);
@@ -881,8 +842,6 @@ __global__ __launch_bounds__(512) void crop8_split_kernel(const float *__restric
         GN_PROBE(1);
       }
       GN_PROBE(2);
-      __syncthreads();
-      GN_PROBE(3);
       if (c >= 0) layer3(c);
       GN_PROBE(6);
       GN_PROBE_COUNT(9, 1);
@@ -1304,8 +1263,8 @@ extern "C" int gn_crop_unique_mlp_pool_split(const float *xyz, const float *seed
     const char *we = getenv("GN_CROP_WAVES");
     const int waves = we ? atoi(we) : 4;
     if (waves == 8) {
-      constexpr int TP8 = 64, RING = 4;
-      constexpr size_t lds8 = 2 * (2 * 3 * TP8 * sp_stride(128) + 3 * TP8 * sp_stride(64)) +
+      constexpr int TP8 = 32, RING = 4;
+      constexpr size_t lds8 = 2 * (2 * 3 * TP8 * sp_stride(128) + 2 * 3 * TP8 * sp_stride(64)) +
                               sizeof(float) * (2 * TP8 * lds_stride(8) + 2 * RING * TP8 * 4 + RING * TP8 + 64 * 4 + 128);
       auto k8 = crop8_split_kernel<64, 128, 256, 4, 256>;
       if ((rc = set_lds_attr(k8, lds8, "crop_unique_mlp_pool_split"))) return rc;

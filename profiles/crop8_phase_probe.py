@@ -29,12 +29,15 @@ for _ in range(4):
 b.record(); torch.cuda.synchronize()
 print("crop kernel, GN_CROP_WAVES=%s (instrumented): %.3f ms per launch" % (os.environ["GN_CROP_WAVES"], a.elapsed_time(b) / 4))
 lib.gn_phase_probe_read_split(buf, 1)
-namesA = ["top", "wait slot bar", "L3+pool", "wait half bar", "L1", "put", "-", "-", "-"]
-namesB = ["top", "wait slot bar", "L2", "wait half bar", "-", "-", "L3+pool", "-", "-"]
+namesA = ["top", "wait slot bar", "L3 pool+close", "-", "L1", "put", "-", "-", "-"]
+namesB = ["top", "wait slot bar", "L2 rest", "-", "-", "-", "L3 pool+close", "-", "-"]
 for w in range(8):
     v = [buf[w * 16 + i] for i in range(16)]
     tot = sum(v[:9])
     if tot == 0:
         continue
+    tot += sum(v[11:16])
+    sub = {11: "L2 mfma+wait", 12: "L2 epilogue", 13: "L3 mfma", 14: "-", 15: "L3 setup"}
+    print("        sub-marks (taken out of their phase): " + "  ".join("%s %.1f%%" % (sub[i], 100.0 * v[i] / tot) for i in range(11, 16) if v[i]))
     print("wave %d: ticks/slot %.0f  slots %d | " % (w, tot / max(v[9], 1), v[9]) +
           "  ".join("%s %.1f%%" % ((namesA if w < 4 else namesB)[i], 100.0 * v[i] / tot) for i in range(9) if v[i]))

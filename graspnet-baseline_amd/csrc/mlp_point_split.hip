@@ -477,10 +477,21 @@ extern "C" int gn_point_linear_split(const float *x, int rows, int cin, int cout
   GN_REQUIRE(x && wpacked && bias && out, "point_linear_split: null pointer");
   PointSplitArgs a{};
   a.w[0] = wpacked; a.b[0] = bias; a.x = x; a.out = out; a.ldo = cout; a.ncols_out = cout; a.nrows = rows;
-  if (cin == 128 && cout == 128)
+  // one layer, ~3 us of MFMA + HBM work per launch: with ONE 64-row workgroup per CU (256 / 128 / 64 tiles at batch 8) a
+  // CU sits through its tile's row fetch, split, weight stream and store one after the other; 32-row tiles, two
+  // workgroups per CU (the default; GN_LINEAR_WPC=1: the 64-row form) let one tile's latencies lie under the other's work
+  const char *le = getenv("GN_LINEAR_WPC");      // read per call: profiles/point_chain_bench.py A/Bs the shapes in one process
+  const int lin_wpc = le ? atoi(le) : 2;          // measured at batch 8: 12.7 / 11.3 / 10.7 -> 10.2 / 10.8 / 9.8 us, outputs identical
+  if (cin == 128 && cout == 128) {
+    if (lin_wpc >= 2)
+      return launch_point_split<PLOAD_PLAIN, 1, 128, 128, 0, 0, 0, 0, 32, false, 2>(a, as_stream(stream), "point_linear_split");
     return launch_point_split<PLOAD_PLAIN, 1, 128, 128, 0, 0, 0, 0, 64, false>(a, as_stream(stream), "point_linear_split");
-  if (cin == 256 && cout == 128)
+  }
+  if (cin == 256 && cout == 128) {
+    if (lin_wpc >= 2)
+      return launch_point_split<PLOAD_PLAIN, 1, 256, 128, 0, 0, 0, 0, 32, false, 2>(a, as_stream(stream), "point_linear_split");
     return launch_point_split<PLOAD_PLAIN, 1, 256, 128, 0, 0, 0, 0, 64, false>(a, as_stream(stream), "point_linear_split");
+  }
   set_error("point_linear_split: unsupported configuration cin=%d cout=%d", cin, cout);
   return GN_ERR_INVALID_ARG;
 }

@@ -74,6 +74,7 @@ for name, out, fn in cases:
     res = {}
     for wpc in ("1", "2"):
         os.environ["GN_POINT_WPC"] = wpc
+        os.environ["GN_LINEAR_WPC"] = wpc
         os.environ["GN_HEADS_DENSE"] = os.environ.get("PCB_DENSE", "0")
         out.zero_()
         fn()

@@ -5,8 +5,12 @@
 //   voxel_down_sample  open3d PointCloud.voxel_down_sample as used by utils/collision_detector.py:32-35
 //                      (un-vendored third party: restated from its documented behaviour -- voxel origin
 //                      = min_bound - voxel/2, index = floor((p-origin)/voxel), output = mean of members;
-//                      PARITY UNPINNED, output order is unspecified there and here)
-//   collision_detect   utils/collision_detector.py:69-129 ModelFreeCollisionDetector.detect
+//                      PARITY UNPINNED upstream; open3d leaves the output order unspecified, here it is the
+//                      order of first appearance and the sums are taken in ascending member order, so the
+//                      result is bit-identical to the sequential numpy restatement and from run to run)
+//                      -- a whole batch of clouds per call, nothing read back
+//   collision_detect   utils/collision_detector.py:69-129 ModelFreeCollisionDetector.detect (one scene for all grasp
+//                      lists as the reference's object holds it, or scene b's own points for grasp list b)
 //   grasp_nms          graspnetAPI GraspGroup.sort_by_score() / .nms() (grasp_nms.nms_grasp; un-vendored,
 //                      PARITY UNPINNED): score-descending greedy suppression of grasps within a
 //                      translation AND rotation-angle threshold of a kept one

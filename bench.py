@@ -663,8 +663,31 @@ def main():
                 torch.cuda.synchronize()
                 return (time.perf_counter() - t0) / n
 
+            def ext_share():
+                """one instrumented forward: HIP-event brackets around every `_ext` call -> ms inside the drop-in operators"""
+                import types
+                evs = []
+                wrapped = types.SimpleNamespace()
+                for name in ("furthest_point_sampling", "gather_points", "ball_query", "group_points", "three_nn",
+                             "three_interpolate", "cylinder_query"):
+                    def mk(fn):
+                        def w(*a):
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record()
+                            r = fn(*a)
+                            e1.record()
+                            evs.append((e0, e1))
+                            return r
+                        return w
+                    setattr(wrapped, name, mk(getattr(DE, name)))
+                with torch.no_grad():
+                    DH.forward(wrapped, sets[0], sdd)
+                torch.cuda.synchronize()
+                return sum(a.elapsed_time(b) for a, b in evs), len(evs)
+
             kd = max(5, min(args.steps, 20))
             td = dropin_time(kd)
+            ext_ms, ext_calls = ext_share()
             os.environ["GN_GRID_CACHE"] = "0"
             td0 = dropin_time(kd)
             os.environ["GN_GRID_CACHE"] = "1"
@@ -672,6 +695,7 @@ def main():
             extra["dropin_unfused_scenes_per_s"] = B / td
             extra["dropin_unfused"] = {"scenes_per_s": B / td, "ms_per_forward": td * 1e3, "steps": kd,
                                        "ms_per_forward_without_grid_reuse": td0 * 1e3,
+                                       "ms_inside_the_ext_operators": ext_ms, "ext_calls_per_forward": ext_calls,
                                        "fraction_of_single_stream_fused": (B / td) / extra.get("single_stream_scenes_per_s", float("nan")),
                                        "note": "unfused reference composition (harness) on torch-GPU layers over the drop-in "
                                                "operators; one stream; the fused path is `single_stream_scenes_per_s`"}

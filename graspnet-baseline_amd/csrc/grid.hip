@@ -294,11 +294,14 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void ball_grid_kernel(const float *_
                                                                   const float *__restrict__ sxyz,
                                                                   const int32_t *__restrict__ sidx, int n, int m,
                                                                   float radius, float hmin, float hmax, float reach,
-                                                                  int nsample, int32_t *__restrict__ idx) {
+                                                                  int nsample, int32_t *__restrict__ idx, int nb) {
   __shared__ int s_queue[GQ_WAVES][128];
-  const int b = blockIdx.y;
+  // XCD-aware workgroup order: consecutive workgroup ids go to consecutive XCDs (8 of them, each with its own L2), so
+  // cloud = id % nb keeps a cloud's workgroups -- and its cell-sorted points -- on nb-th of the XCDs (one XCD per cloud at
+  // batch 8) instead of every XCD fetching every cloud (PMC: 4-5x the compulsory bytes, profiles/r4_pmc_traffic.json)
+  const int b = blockIdx.x % nb;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int j = blockIdx.x * GQ_WAVES + wv;
+  const int j = (blockIdx.x / nb) * GQ_WAVES + wv;
   if (j >= m) return;
   const GridHeader H = hdr[b];
   cell_start += (size_t)b * GRID_CS_STRIDE;
@@ -404,12 +407,12 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void cylinder_unique_grid_kernel(
     const float *__restrict__ new_xyz, const float *__restrict__ rot, const GridHeader *__restrict__ hdr,
     const int *__restrict__ cell_start, const float *__restrict__ sxyz, const int32_t *__restrict__ sidx, int n, int m,
     float radius, float hmin, float hmax0, float hmax1, float hmax2, float hmax3, float reach, int nsample,
-    int32_t *__restrict__ uidx, int32_t *__restrict__ ucount) {
+    int32_t *__restrict__ uidx, int32_t *__restrict__ ucount, int nb) {
   static_assert(ND == 4, "4 depths");
   __shared__ int s_queue[GQ_WAVES][ND][128];
-  const int b = blockIdx.y;
+  const int b = blockIdx.x % nb;          // XCD-aware order, see ball_grid_kernel
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int j = blockIdx.x * GQ_WAVES + wv;
+  const int j = (blockIdx.x / nb) * GQ_WAVES + wv;
   if (j >= m) return;
   const GridHeader H = hdr[b];
   cell_start += (size_t)b * GRID_CS_STRIDE;
@@ -579,9 +582,10 @@ extern "C" int gn_ball_query_grid(const float *new_xyz, const void *grid, int b,
   GN_REQUIRE(b <= 65535, "ball_query_grid: batch > 65535 unsupported");
   GridHeader *hdr; int *cs; float *sxyz; int32_t *sidx;
   grid_carve(const_cast<void *>(grid), b, n, &hdr, &cs, &sxyz, &sidx);
-  dim3 g((m + GQ_WAVES - 1) / GQ_WAVES, b);
+  GN_REQUIRE((long)((m + GQ_WAVES - 1) / GQ_WAVES) * b < 0x7fffffffL, "ball_query_grid: too many centres");
+  dim3 g((unsigned)((m + GQ_WAVES - 1) / GQ_WAVES) * b);
   hipLaunchKernelGGL(ball_grid_kernel<false>, g, dim3(GQ_WAVES * 64), 0, as_stream(stream), new_xyz, (const float *)nullptr,
-                     hdr, cs, sxyz, sidx, n, m, radius, 0.f, 0.f, radius, nsample, idx);
+                     hdr, cs, sxyz, sidx, n, m, radius, 0.f, 0.f, radius, nsample, idx, b);
   GN_CHECK_LAUNCH("ball_query_grid");
   return GN_OK;
 }
@@ -597,9 +601,10 @@ extern "C" int gn_cylinder_query_grid(const float *new_xyz, const float *rot, co
   // every hit lies within this distance of the centre: radial < radius, axial in (hmin, hmax)
   const float ax = fmaxf(fabsf(hmin), fabsf(hmax));
   const float reach = sqrtf(radius * radius + ax * ax) * 1.0001f;
-  dim3 g((m + GQ_WAVES - 1) / GQ_WAVES, b);
+  GN_REQUIRE((long)((m + GQ_WAVES - 1) / GQ_WAVES) * b < 0x7fffffffL, "cylinder_query_grid: too many centres");
+  dim3 g((unsigned)((m + GQ_WAVES - 1) / GQ_WAVES) * b);
   hipLaunchKernelGGL(ball_grid_kernel<true>, g, dim3(GQ_WAVES * 64), 0, as_stream(stream), new_xyz, rot, hdr, cs, sxyz, sidx,
-                     n, m, radius, hmin, hmax, reach, nsample, idx);
+                     n, m, radius, hmin, hmax, reach, nsample, idx, b);
   GN_CHECK_LAUNCH("cylinder_query_grid");
   return GN_OK;
 }
@@ -620,10 +625,11 @@ extern "C" int gn_cylinder_query_unique_grid(const float *new_xyz, const float *
   // every hit lies within this distance of the seed: radial <= radius, axial in (hmin, hmax]
   const float ax = fmaxf(fabsf(hmin), fabsf(hmax_host[3]));
   const float reach = sqrtf(radius * radius + ax * ax) * 1.0001f;
-  dim3 g((m + GQ_WAVES - 1) / GQ_WAVES, b);
+  GN_REQUIRE((long)((m + GQ_WAVES - 1) / GQ_WAVES) * b < 0x7fffffffL, "cylinder_query_unique_grid: too many seeds");
+  dim3 g((unsigned)((m + GQ_WAVES - 1) / GQ_WAVES) * b);
   hipLaunchKernelGGL((cylinder_unique_grid_kernel<4>), g, dim3(GQ_WAVES * 64), 0, as_stream(stream), new_xyz, rot, hdr,
                      cs, sxyz, sidx, n, m, radius, hmin, hmax_host[0], hmax_host[1], hmax_host[2], hmax_host[3], reach,
-                     nsample, uidx, ucount);
+                     nsample, uidx, ucount, b);
   GN_CHECK_LAUNCH("cylinder_query_unique_grid");
   return GN_OK;
 }

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(NWV * 64) void crop_packed_split_kernel(const float
                                                                         const int32_t *__restrict__ uidx,
                                                                         const int32_t *__restrict__ ucount, int m,
                                                                         int nseeds, int spb, SplitWeights W,
-                                                                        float *__restrict__ out) {
+                                                                        float *__restrict__ out, int nb) {
   constexpr int CIN0 = 8, XS0 = lds_stride(CIN0), MT = TP / 32;
   static_assert(MT == 3, "the layer-3 walk below is written out for three M tiles per chunk");
   constexpr int P2 = TP * sp_stride(C2), P1 = TP * sp_stride(C1);
@@ -272,7 +272,10 @@ __global__ __launch_bounds__(NWV * 64) void crop_packed_split_kernel(const float
   PoolMasked<ND, NTW> pool{bufGA, lane, {}};
   pool.reset();
 
-  const int s0 = blockIdx.x * spb;
+  // XCD-aware workgroup order (nb > 0: the grid holds nb clouds of gridDim.x / nb workgroups each): consecutive workgroup
+  // ids go to consecutive XCDs, so cloud = id % nb keeps a cloud's workgroups -- and its coordinates -- in one XCD's L2
+  const int wg = nb > 0 ? (int)(blockIdx.x % nb) * (int)(gridDim.x / nb) + (int)(blockIdx.x / nb) : (int)blockIdx.x;
+  const int s0 = wg * spb;
   const int nsd = min(nseeds, s0 + spb) - s0;       // seed slots of this workgroup (<= kCropMaxSpb)
   if (nsd <= 0) return;
   if (tid <= kCropMaxSpb) s_off[tid] = (tid >= 1 && tid <= nsd) ? ucount[s0 + tid - 1] : 0;
@@ -576,7 +579,7 @@ template <int C1, int C2, int C3, int ND, int CAP>
 __global__ __launch_bounds__(512) void crop8_split_kernel(const float *__restrict__ xyz, int n, const float *__restrict__ seed,
                                                           const float *__restrict__ rot, const int32_t *__restrict__ uidx,
                                                           const int32_t *__restrict__ ucount, int m, int nseeds, int spb,
-                                                          SplitWeights W, float *__restrict__ out) {
+                                                          SplitWeights W, float *__restrict__ out, int nb) {
   constexpr int TP = 32, NWV = 8, CIN0 = 8, XS0 = lds_stride(CIN0), RING = 4;
   static_assert(C1 == 64 && C2 == 128 && C3 == 256, "written for CloudCrop's 64-128-256 layers");
   constexpr int P2 = TP * sp_stride(C2), P1 = TP * sp_stride(C1);
@@ -615,7 +618,8 @@ __global__ __launch_bounds__(512) void crop8_split_kernel(const float *__restric
   PoolMasked<ND, 1> pool{bufGA, lane, {}};
   pool.reset();
 
-  const int s0 = blockIdx.x * spb;
+  const int wg = nb > 0 ? (int)(blockIdx.x % nb) * (int)(gridDim.x / nb) + (int)(blockIdx.x / nb) : (int)blockIdx.x;   // XCD-aware
+  const int s0 = wg * spb;
   const int nsd = min(nseeds, s0 + spb) - s0;
   if (nsd <= 0) return;
   if (tid <= kCropMaxSpb) s_off[tid] = (tid >= 1 && tid <= nsd) ? ucount[s0 + tid - 1] : 0;
@@ -860,7 +864,7 @@ __global__ __launch_bounds__(MLP_THREADS, MINW) void sa_xyz_split_kernel(const f
                                                                    const float *__restrict__ new_xyz,
                                                                    const int32_t *__restrict__ idx, int np, int ntiles,
                                                                    int tpb, float radius, SplitWeights W,
-                                                                   float *__restrict__ out) {
+                                                                   float *__restrict__ out, int nb) {
   constexpr int GPT = TP / NS, XS0 = lds_stride(8);
   static_assert(GPT >= 1, "a tile holds whole groups");
   constexpr int P1 = TP * sp_stride(C1), P2 = TP * sp_stride(C2);
@@ -883,8 +887,11 @@ __global__ __launch_bounds__(MLP_THREADS, MINW) void sa_xyz_split_kernel(const f
   load_bias_t(W.b2, wave % L2::WN, lane, b2t);
 #pragma unroll
   for (int i = 0; i < L3::NTW; ++i) b3[i] = W.b3[((wave % L3::WN) * L3::NTW + i) * 32 + (lane & 31)];
-  const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * tpb);
-  int tile = blockIdx.x * tpb;
+  // XCD-aware workgroup order (nb > 0: nb clouds of gridDim.x / nb workgroups each): cloud = workgroup id % nb, so a cloud's
+  // coordinates / per-point rows stay in one XCD's L2 instead of being fetched by all eight
+  const int wgx = nb > 0 ? (int)(blockIdx.x % nb) * (int)(gridDim.x / nb) + (int)(blockIdx.x / nb) : (int)blockIdx.x;
+  const int tile_end = min(ntiles, (wgx + 1) * tpb);
+  int tile = wgx * tpb;
   if (tile >= tile_end) return;
   // the neighbour index of the tile after next is loaded while the next tile's coordinates are gathered (see the
   // hoisted kernel below)
@@ -971,7 +978,7 @@ __global__ __launch_bounds__(NWV * 64) void sa_hoist_split_kernel(const float *_
                                                                      const float *__restrict__ new_xyz,
                                                                      const int32_t *__restrict__ idx, int np, int ntiles,
                                                                      int tpb, float radius, SplitWeights W,
-                                                                     float *__restrict__ out) {
+                                                                     float *__restrict__ out, int nb) {
   constexpr int TP = 64, MT = TP / 32, GPT = TP / NS, XS0 = lds_stride(8);
   constexpr int P1 = TP * sp_stride(C1), P2 = TP * sp_stride(C2);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -997,8 +1004,11 @@ __global__ __launch_bounds__(NWV * 64) void sa_hoist_split_kernel(const float *_
   load_bias_t(W.b2, wave % L2::WN, lane, b2t);
 #pragma unroll
   for (int i = 0; i < L3::NTW; ++i) b3[i] = W.b3[((wave % L3::WN) * L3::NTW + i) * 32 + (lane & 31)];
-  const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * tpb);
-  int tile = blockIdx.x * tpb;
+  // XCD-aware workgroup order (nb > 0: nb clouds of gridDim.x / nb workgroups each): cloud = workgroup id % nb, so a cloud's
+  // coordinates / per-point rows stay in one XCD's L2 instead of being fetched by all eight
+  const int wgx = nb > 0 ? (int)(blockIdx.x % nb) * (int)(gridDim.x / nb) + (int)(blockIdx.x / nb) : (int)blockIdx.x;
+  const int tile_end = min(ntiles, (wgx + 1) * tpb);
+  int tile = wgx * tpb;
   if (tile >= tile_end) return;
 
   // The neighbour indices are fetched one tile ahead of the rows they address (two tiles ahead of their use): a row
@@ -1171,8 +1181,10 @@ extern "C" int gn_sa_group_mlp_pool_split(const float *xyz, const float *new_xyz
     const size_t lds = 2 * (size_t)(3 * tp * sp_stride(64) + 3 * tp * sp_stride(64)) + sizeof(float) * (2 * tp * lds_stride(8));
     if ((rc = set_lds_attr(k, lds, "sa_group_mlp_pool_split"))) return;
     const int tpb = split_tiles_per_block(ntiles, 4);
+    const int per_cloud = ntiles / b;                              // tiles of one cloud
+    const int nbx = (b > 1 && per_cloud % tpb == 0) ? b : 0;       // every cloud a whole number of workgroups -> XCD-aware order
     hipLaunchKernelGGL(k, dim3((ntiles + tpb - 1) / tpb), dim3(MLP_THREADS), lds, as_stream(stream), xyz, n, new_xyz, idx,
-                       np, ntiles, tpb, radius, W, out);
+                       np, ntiles, tpb, radius, W, out, nbx);
   };
   if (variant == 1) {          // one group per tile, two workgroups per CU: one's epilogues and barriers under the other's MFMAs
     launch(sa_xyz_split_kernel<64, 64, 128, 64, 64, 2>, 64);
@@ -1206,8 +1218,10 @@ extern "C" int gn_sa_hoisted_mlp_pool_split(const float *xyz, const float *pfeat
   int rc;
   auto launch = [&](auto k, int threads) {
     if ((rc = set_lds_attr(k, lds, "sa_hoisted_mlp_pool_split"))) return;
+    const int per_cloud = ntiles / b;
+    const int nbx = (b > 1 && per_cloud * b == ntiles && per_cloud % tpb == 0) ? b : 0;
     hipLaunchKernelGGL(k, dim3((ntiles + tpb - 1) / tpb), dim3(threads), lds, as_stream(stream), xyz, n, pfeat, new_xyz, idx,
-                       np, ntiles, tpb, radius, W, out);
+                       np, ntiles, tpb, radius, W, out, nbx);
   };
   rc = GN_OK;
   // (an 8-wave flavour, two waves per SIMD with half the weights each, needs ~270 registers per lane and spills)
@@ -1253,10 +1267,12 @@ extern "C" int gn_crop_unique_mlp_pool_split(const float *xyz, const float *seed
                                 sizeof(float) * (2 * (TP + 1) * lds_stride(8) + 2 * 3 * TP * 4 + 2 * TP + 64 * 4) + 2 * 3 * 64 * 8;
   if (packed) {
     static const int ride = []() { const char *e = getenv("GN_CROP_RIDE"); return e ? atoi(e) : 1; }();
+    // every cloud a whole number of workgroups -> XCD-aware order (cloud = workgroup id % b)
+    const int nbx = (m % spb == 0 && b > 1) ? b : 0;
     auto go = [&](auto k) {
       if ((rc = set_lds_attr(k, lds_packed, "crop_unique_mlp_pool_split"))) return;
       hipLaunchKernelGGL(k, dim3((nseeds + spb - 1) / spb), dim3(MLP_THREADS), lds_packed, as_stream(stream), xyz, n, seed_xyz,
-                         rot, uidx, ucount, m, nseeds, spb, W, out);
+                         rot, uidx, ucount, m, nseeds, spb, W, out, nbx);
     };
     // GN_CROP_WAVES=8: the 8-wave form -- two waves per SIMD, every wave ONE n-tile of layer 3 and one of layer 2 resident
     // (144 of its 256 registers), one wave's epilogues / pooling / staging under its SIMD partner's MFMAs
@@ -1269,7 +1285,7 @@ extern "C" int gn_crop_unique_mlp_pool_split(const float *xyz, const float *seed
       auto k8 = crop8_split_kernel<64, 128, 256, 4, 256>;
       if ((rc = set_lds_attr(k8, lds8, "crop_unique_mlp_pool_split"))) return rc;
       hipLaunchKernelGGL(k8, dim3((nseeds + spb - 1) / spb), dim3(512), lds8, as_stream(stream), xyz, n, seed_xyz, rot, uidx,
-                         ucount, m, nseeds, spb, W, out);
+                         ucount, m, nseeds, spb, W, out, nbx);
     }
     else if (ride) go(crop_packed_split_kernel<64, 128, 256, 4, 256, TP, true>);
     else go(crop_packed_split_kernel<64, 128, 256, 4, 256, TP, false>);

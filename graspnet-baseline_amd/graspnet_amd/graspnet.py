@@ -516,9 +516,11 @@ class PipelinedGraspNet:
         def __init__(self, end_points, grasps, counts, event, stream):
             self.end_points, self.grasps, self.counts, self.event, self.stream = end_points, grasps, counts, event, stream
 
+        final_rows = kept = collision_mask = None      # set when the pipeline was built with post=...
+
         def _tensors(self):
             priv = self.end_points.get("_gn") or {}
-            vals = list(self.end_points.values()) + list(priv.values())
+            vals = list(self.end_points.values()) + list(priv.values()) + [self.final_rows, self.kept, self.collision_mask]
             return [self.grasps, self.counts] + [v for v in vals if torch.is_tensor(v) and v.is_cuda]
 
         def _register(self, cur):
@@ -542,8 +544,12 @@ class PipelinedGraspNet:
             self._register(torch.cuda.current_stream(self.grasps.device))
             return self.end_points, self.grasps, self.counts
 
-    def __init__(self, net, depth=12):
+    def __init__(self, net, depth=12, post=None):
+        """post: None, or a dict of postprocess.grasp_pipeline() keyword arguments: every submitted batch then also goes through
+        the collision filter + sort + NMS on its stream (no host read), and the ticket carries `final_rows` (B,M,17), `kept` (B,)
+        and `collision_mask` (B,M) beside the raw grasps."""
         self.net = net
+        self.post = None if post is None else dict(post)
         self.streams = [torch.cuda.Stream(device=net.device) for _ in range(max(1, int(depth)))]
         self._i = 0
 
@@ -554,10 +560,17 @@ class PipelinedGraspNet:
         with torch.cuda.stream(st):
             ep = self.net({"point_clouds": point_clouds})
             grasps, counts = self.net.decode_padded(ep)
+            tail = None
+            if self.post is not None:
+                from . import postprocess
+                tail = postprocess.grasp_pipeline(point_clouds[..., 0:3], grasps, counts, **self.post)
             ev = torch.cuda.Event()
             ev.record(st)
         point_clouds.record_stream(st)
-        return PipelinedGraspNet.Ticket(ep, grasps, counts, ev, st)
+        t = PipelinedGraspNet.Ticket(ep, grasps, counts, ev, st)
+        if tail is not None:
+            t.final_rows, t.kept, t.collision_mask = tail
+        return t
 
 
 _NO_HOOK = L.STAGE_HOOK()      # NULL function pointer

@@ -287,6 +287,24 @@ def test_full_pipeline_is_graph_capturable_and_sync_free(state_dict):
     assert all(0 < k[b] < int(c[b]) for b in range(4))
 
 
+def test_pipelined_batches_with_post_processing(state_dict):
+    """PipelinedGraspNet(post=...): every batch's collision filter + sort + NMS rides on the batch's own stream; the tickets'
+    final rows equal the one-at-a-time result"""
+    from graspnet_amd import GraspNet, PipelinedGraspNet, postprocess as P, synthetic as S
+    net = GraspNet().load_state_dict(state_dict)
+    args = dict(voxel_size=0.01, approach_dist=0.05, collision_thresh=0.01)
+    batches = [S.make_batch(1000 + 2 * i, 2, 20000, "surface").cuda() for i in range(5)]
+    pipe = PipelinedGraspNet(net, depth=3, post=args)
+    tickets = [pipe.submit(x) for x in batches]
+    for x, t in zip(batches, tickets):
+        t.result()
+        g, c = net.decode_padded(net({"point_clouds": x}))
+        rows, kept, cm = P.grasp_pipeline(x, g, c, **args)
+        torch.cuda.synchronize()
+        assert torch.equal(t.kept, kept) and torch.equal(t.final_rows, rows) and torch.equal(t.collision_mask, cm)
+        assert int(kept.min()) > 0
+
+
 def test_collision_detector_matches_reference_formula(scene, grasps):
     from graspnet_amd import postprocess as P
     from oracle import post_oracle as PO

@@ -721,3 +721,60 @@ extern "C" int gn_grasp_nms(const float *grasps, const int32_t *counts, const ui
   GN_CHECK_LAUNCH("grasp_nms");
   return GN_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// the whole post-processing of a batch in ONE call (what test.py:88-96 / demo_pointcloud.py:228-249 run on the host per
+// scene after pred_decode): voxel down-sample of every scene's cloud -> collision check of scene b's grasps against scene
+// b's points -> collisions dropped, sort by score (+ NMS).  One workspace, ~13 launches on the caller's stream, nothing
+// read back, hipGraph-capturable.
+// ------------------------------------------------------------------------------------------------
+namespace gn {
+struct PostWs {
+  void *voxel;
+  double *scene;
+  int32_t *scene_counts, *status;
+  uint8_t *cmask;
+  void *nms;
+  size_t bytes;
+};
+static PostWs post_carve(void *base, int b, int n, int mpad) {
+  char *p = static_cast<char *>(base);
+  size_t o = 0;
+  auto take = [&](size_t bytes) { char *q = p ? p + o : nullptr; o += (bytes + 255) & ~(size_t)255; return q; };
+  PostWs w;
+  w.voxel = take(gn_voxel_batched_workspace_bytes(b, n));
+  w.scene = (double *)take((size_t)b * (n > 0 ? n : 1) * 3 * sizeof(double));
+  w.scene_counts = (int32_t *)take((size_t)b * sizeof(int32_t));
+  w.status = (int32_t *)take((size_t)b * sizeof(int32_t));
+  w.cmask = (uint8_t *)take((size_t)b * (mpad > 0 ? mpad : 1));
+  w.nms = take(gn_grasp_nms_workspace_bytes(b));
+  w.bytes = o;
+  return w;
+}
+}  // namespace gn
+
+extern "C" size_t gn_grasp_postprocess_workspace_bytes(int b, int n, int mpad) {
+  if (b <= 0 || n < 0 || mpad < 0) return 0;
+  return post_carve(nullptr, b, n, mpad).bytes;
+}
+
+extern "C" int gn_grasp_postprocess(const float *clouds, const int32_t *n_valid, int b, int n, const float *grasps,
+                                    const int32_t *counts, int mpad, double voxel_size, float approach_dist,
+                                    double collision_thresh, double translation_thresh, double rotation_thresh, int do_nms,
+                                    void *workspace, float *out_rows, int32_t *out_counts, uint8_t *collision_mask,
+                                    int32_t *voxel_status, gn_stream_t stream) {
+  GN_REQUIRE(b >= 0 && n >= 0 && mpad >= 0 && voxel_size > 0.0, "grasp_postprocess: bad sizes");
+  if (b == 0) return GN_OK;
+  GN_REQUIRE(clouds && grasps && workspace && out_rows && out_counts, "grasp_postprocess: null pointer");
+  GN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "grasp_postprocess: workspace must be 256-byte aligned");
+  const PostWs w = post_carve(workspace, b, n, mpad);
+  uint8_t *cm = collision_mask ? collision_mask : w.cmask;
+  int32_t *st = voxel_status ? voxel_status : w.status;
+  if (int rc = gn_voxel_down_sample_batched(clouds, n_valid, b, n, voxel_size, w.voxel, w.scene, w.scene_counts, st, stream)) return rc;
+  // the detector's finger geometry: utils/collision_detector.py:29-30
+  if (int rc = gn_collision_detect_batched(w.scene, n, w.scene_counts, grasps, counts, b, mpad, approach_dist, collision_thresh,
+                                           0.01, voxel_size, 0.01f, 0.06f, cm, nullptr, nullptr, stream))
+    return rc;
+  return gn_grasp_nms(grasps, counts, cm, b, mpad, translation_thresh, rotation_thresh, do_nms, w.nms, out_rows, out_counts,
+                      stream);
+}

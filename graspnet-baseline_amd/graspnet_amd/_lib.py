@@ -138,6 +138,10 @@ SIGNATURES = {
     "gn_grasp_nms_workspace_bytes": (_c_size_t, [_c_int]),
     "gn_grasp_nms": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, ctypes.c_double, ctypes.c_double, _c_int,
                               _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "gn_grasp_postprocess_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
+    "gn_grasp_postprocess": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, ctypes.c_double,
+                                      _c_float, ctypes.c_double, ctypes.c_double, ctypes.c_double, _c_int, _c_void_p, _c_void_p,
+                                      _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "gn_graspnet_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
     "gn_graspnet_forward": (_c_int, [ctypes.POINTER(Weights), _c_void_p, _c_int, _c_int, _c_void_p, ctypes.POINTER(Outputs),
                                      STAGE_HOOK, _c_void_p, _c_void_p]),

@@ -277,8 +277,22 @@ def grasp_pipeline(clouds, grasps, counts, voxel_size=0.01, approach_dist=0.05, 
     ~12 launches, no host read, no allocation besides torch's caching allocator, hipGraph-capturable.
     clouds (B,N,3) f32, grasps (B,M,17) + counts (B,) as GraspNet.decode_padded() leaves them ->
     (rows (B,M,17) sorted by score with zero padding, kept (B,) i32, collision mask (B,M) bool)."""
-    det = BatchedCollisionDetector(clouds, voxel_size, n_valid)
-    cm = det.detect_padded(grasps, counts, approach_dist=approach_dist, collision_thresh=collision_thresh)
-    out, oc = sort_and_nms(grasps, counts, drop_mask=cm, translation_thresh=translation_thresh,
-                           rotation_thresh=rotation_thresh, nms=nms)
-    return out, oc, cm
+    if not (clouds.is_cuda and grasps.is_cuda):
+        raise RuntimeError("CPU not supported")
+    clouds = clouds.to(torch.float32).contiguous()
+    grasps = grasps.contiguous()
+    B, n = clouds.shape[0], clouds.shape[1]
+    M = grasps.shape[1]
+    dev = grasps.device
+    lib = L.lib()
+    ws = torch.empty((max(lib.gn_grasp_postprocess_workspace_bytes(B, n, M), 256),), dtype=torch.uint8, device=dev)
+    out = torch.empty_like(grasps)
+    oc = torch.empty((B,), dtype=torch.int32, device=dev)
+    cm = torch.empty((B, M), dtype=torch.uint8, device=dev)
+    nv = None if n_valid is None else n_valid.to(device=dev, dtype=torch.int32).contiguous()
+    with torch.cuda.device(dev):      # ONE C call: voxel down-sample -> collision detect -> sort (+ NMS)
+        L.check(lib.gn_grasp_postprocess(clouds.data_ptr(), L.ptr(nv), B, n, grasps.data_ptr(), L.ptr(counts), M, float(voxel_size),
+                                         float(approach_dist), float(collision_thresh), float(translation_thresh),
+                                         float(rotation_thresh), 1 if nms else 0, ws.data_ptr(), out.data_ptr(), oc.data_ptr(),
+                                         cm.data_ptr(), None, _stream(grasps)), "grasp_postprocess")
+    return out, oc, cm.view(torch.bool)

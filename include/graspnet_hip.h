@@ -436,6 +436,18 @@ int gn_grasp_nms(const float *grasps, const int32_t *counts, const uint8_t *drop
                  double translation_thresh, double rotation_thresh, int do_nms, void *workspace, float *out,
                  int32_t *out_counts, gn_stream_t stream);
 
+/* The three steps above for a whole batch in ONE call -- what test.py:88-96 / demo_pointcloud.py:228-249 run on the host
+ * per scene after pred_decode: clouds (B,n,3) f32 (n_valid (B) or NULL) are voxel-down-sampled, scene b's padded grasp rows
+ * (B,mpad,17) + counts (B) are checked against scene b's points (finger geometry of collision_detector.py:29-30), the
+ * collisions dropped and the rest sorted by score (+ greedy NMS).  out_rows (B,mpad,17) padded with zero rows, out_counts (B);
+ * collision_mask (B,mpad) u8 and voxel_status (B) may be NULL.  ~13 launches on `stream`, no host read. */
+size_t gn_grasp_postprocess_workspace_bytes(int b, int n, int mpad);
+int gn_grasp_postprocess(const float *clouds, const int32_t *n_valid, int b, int n, const float *grasps,
+                         const int32_t *counts, int mpad, double voxel_size, float approach_dist,
+                         double collision_thresh, double translation_thresh, double rotation_thresh, int do_nms,
+                         void *workspace /* 256-byte aligned */, float *out_rows, int32_t *out_counts,
+                         uint8_t *collision_mask, int32_t *voxel_status, gn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -193,6 +193,10 @@ def test_collision_detect_batched_equals_one_detector_per_scene(state_dict):
         assert np.array_equal(cm[b, :counts[b]].cpu().numpy(), wcm) and np.array_equal(em[b, :counts[b]].cpu().numpy(), wem)
         assert not cm[b, counts[b]:].any()
     assert len({int(cm[b].sum()) for b in range(B)}) > 1          # the scenes really differ
+    # the one-call form (gn_grasp_postprocess: voxel -> collision -> sort + NMS in one C call) == the three pieces
+    rows, kept, cm3 = P.grasp_pipeline(clouds, g, c, voxel_size=0.01, approach_dist=0.05, collision_thresh=0.01)
+    want_rows, want_kept = P.sort_and_nms(g, c, drop_mask=cm, nms=True)
+    assert torch.equal(cm3, cm) and torch.equal(kept, want_kept) and torch.equal(rows, want_rows)
 
 
 def test_post_processing_edge_cases():

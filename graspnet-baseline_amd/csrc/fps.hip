@@ -944,6 +944,43 @@ static int fps_cell_forced(int n) {
 
 }  // namespace gn
 
+namespace gn {
+// Is `pts2` (n2 points per cloud) exactly the points a previous sampling call picked, in its order -- pts1[inds1[0 .. n2)]?
+// Then the tie step that call reported carries over (tie2 = tie1), else the new cloud is unrelated (tie2 = 0: no promise).
+// One workgroup per cloud, bitwise compare.
+__global__ __launch_bounds__(256) void fps_prefix_check_kernel(const float *__restrict__ pts2, const float *__restrict__ pts1,
+                                                               const int32_t *__restrict__ inds1, const int32_t *__restrict__ tie1,
+                                                               int n2, int n1, int m1, int32_t *__restrict__ tie2) {
+  __shared__ int s_bad;
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
+  const unsigned *p2 = reinterpret_cast<const unsigned *>(pts2) + (size_t)b * n2 * 3;
+  const unsigned *p1 = reinterpret_cast<const unsigned *>(pts1) + (size_t)b * n1 * 3;
+  const int32_t *ix = inds1 + (size_t)b * m1;
+  bool bad = false;
+  for (int i = threadIdx.x; i < n2; i += 256) {
+    const int k = ix[i];
+    if (k < 0 || k >= n1) { bad = true; continue; }
+    bad |= p2[i * 3] != p1[k * 3] || p2[i * 3 + 1] != p1[k * 3 + 1] || p2[i * 3 + 2] != p1[k * 3 + 2];
+  }
+  if (bad) s_bad = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) tie2[b] = s_bad ? 0 : tie1[b];
+}
+}  // namespace gn
+
+extern "C" int gn_fps_prefix_check(const float *pts2, const float *pts1, const int32_t *inds1, const int32_t *tie1, int b, int n2,
+                                   int n1, int m1, int32_t *tie2, gn_stream_t stream) {
+  using namespace gn;
+  GN_REQUIRE(b >= 0 && n2 >= 1 && n1 >= 1 && m1 >= n2, "fps_prefix_check: bad sizes (the earlier call must have picked >= n2 samples)");
+  if (b == 0) return GN_OK;
+  GN_REQUIRE(pts2 && pts1 && inds1 && tie1 && tie2, "fps_prefix_check: null pointer");
+  hipLaunchKernelGGL(fps_prefix_check_kernel, dim3(b), dim3(256), 0, as_stream(stream), pts2, pts1, inds1, tie1, n2, n1, m1, tie2);
+  GN_CHECK_LAUNCH("fps_prefix_check");
+  return GN_OK;
+}
+
 extern "C" size_t gn_fps_workspace_bytes(int b, int n) {
   if (b <= 0 || n <= 0) return 0;
   const int bs = gn::fps_ref_block_size(n);

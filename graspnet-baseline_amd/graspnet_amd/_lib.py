@@ -48,6 +48,8 @@ SIGNATURES = {
     "gn_last_error": (ctypes.c_char_p, []),
     "gn_version": (ctypes.c_char_p, []),
     "gn_fps_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
+    "gn_fps_prefix_check": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p,
+                                     _c_void_p]),
     "gn_furthest_point_sampling": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                            _c_void_p, _c_void_p]),
     "gn_gather_points": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),

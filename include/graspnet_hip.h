@@ -70,6 +70,12 @@ const char *gn_version(void);
  *                       prefix (provably what the full computation returns,
  *                       models/backbone.py:110-119) and is written directly. */
 size_t gn_fps_workspace_bytes(int b, int n);
+/* For callers that chain sampling calls WITHOUT the fused path (the reference model does: backbone.py:105-121 samples the
+ * 2048 sampled points again for 1024, ...): tie2[b] = tie1[b] if pts2 (B,n2,3) is bit for bit pts1[inds1[0..n2)] -- the
+ * points an earlier call on pts1 (B,n1,3) picked, in its order, inds1 (B,m1>=n2), tie1 its tie_out -- else 0.  tie2 is then a
+ * valid `prefix_ok` for sampling pts2 (and a valid tie1 for the next link of the chain). */
+int gn_fps_prefix_check(const float *pts2, const float *pts1, const int32_t *inds1, const int32_t *tie1, int b, int n2,
+                        int n1, int m1, int32_t *tie2, gn_stream_t stream);
 int gn_furthest_point_sampling(const float *xyz, int b, int n, int m, void *workspace,
                                int32_t *idx, float *new_xyz, int32_t *tie_out, const int32_t *prefix_ok,
                                gn_stream_t stream);

@@ -109,3 +109,66 @@ def test_consecutive_queries_on_one_cloud_share_one_grid(run, monkeypatch):
     side.synchronize()
     assert len(builds) == n0 + 1 and torch.equal(d, c)
     E.clear_grid_cache()
+
+
+def test_chained_sampling_calls_take_the_identity_prefix_shortcut(oracle, monkeypatch):
+    """backbone.py:105-121 samples the sampled points again (2048 -> 1024 -> 512 -> 256).  The drop-in remembers its last call
+    per stream; a call whose input is bit for bit the points that call picked inherits its tie step and writes the identity
+    prefix at once (or warm-starts behind the tie) -- same indices as the oracle's full chains, as with GN_FPS_CHAIN=0; an input
+    that only LOOKS related (indices edited in place, another cloud of the same shape) gets no promise and is still right"""
+    from graspnet_amd import pointnet2_ext as E, synthetic as S
+    x = torch.stack([torch.from_numpy(S.make_cloud(1000, 20000, "uniform")), torch.from_numpy(S.make_cloud(1001, 20000, "surface")),
+                     torch.from_numpy(S.make_cloud(1007, 20000, "uniform"))], 0)
+    xd = x.cuda()
+
+    def chain(xd):
+        lv, res = xd, []
+        for m in (2048, 1024, 512, 256):
+            inds = E.furthest_point_sampling(lv, m)
+            res.append(inds)
+            lv = E.gather_points(lv.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+        return res
+    E.clear_fps_chain()
+    got = chain(xd)
+    lv = x
+    for m, g in zip((2048, 1024, 512, 256), got):
+        want = oracle.furthest_point_sampling(lv, m)
+        assert torch.equal(g.cpu(), want), m
+        lv = oracle.gather_points(lv.transpose(1, 2).contiguous(), want).transpose(1, 2).contiguous()
+    assert torch.equal(got[1][0].cpu(), torch.arange(1024, dtype=torch.int32))          # scene 0: no tie -> identity prefix
+    monkeypatch.setenv("GN_FPS_CHAIN", "0")
+    ref = chain(xd)
+    monkeypatch.setenv("GN_FPS_CHAIN", "1")
+    assert all(torch.equal(a, b) for a, b in zip(got, ref))
+    # the shortcut is a shortcut: the second link with the promise against without (same run, a ratio, not an absolute time)
+    lv1 = E.gather_points(xd.transpose(1, 2).contiguous(), got[0]).transpose(1, 2).contiguous()
+
+    def timed(chain_on):
+        monkeypatch.setenv("GN_FPS_CHAIN", "1" if chain_on else "0")
+        ts = []
+        for _ in range(3):
+            E.clear_fps_chain()
+            E.furthest_point_sampling(xd, 2048)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            r = E.furthest_point_sampling(lv1, 1024)
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        return min(ts), r
+    t_on, r_on = timed(True)
+    t_off, r_off = timed(False)
+    monkeypatch.setenv("GN_FPS_CHAIN", "1")
+    assert torch.equal(r_on, r_off) and t_on < 0.7 * t_off, (t_on, t_off)
+    # indices edited in place after the first call: the remembered call no longer describes them -> no promise, full chain
+    E.clear_fps_chain()
+    i1 = E.furthest_point_sampling(xd, 2048)
+    i1[:, 5] = i1[:, 7]
+    lvx = E.gather_points(xd.transpose(1, 2).contiguous(), i1).transpose(1, 2).contiguous()
+    assert torch.equal(E.furthest_point_sampling(lvx, 1024).cpu(), oracle.furthest_point_sampling(lvx.cpu(), 1024))
+    # an unrelated cloud of the right shape right after a sampling call
+    E.clear_fps_chain()
+    E.furthest_point_sampling(xd, 2048)
+    other = S.make_batch(4000, 3, 2048, "uniform")
+    assert torch.equal(E.furthest_point_sampling(other.cuda(), 1024).cpu(), oracle.furthest_point_sampling(other, 1024))
+    E.clear_fps_chain()

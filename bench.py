@@ -360,14 +360,14 @@ def main():
                          "ramp or a clock dip moves a single sample by 10 %%")
     ap.add_argument("--legs", default="all",
                     help="all | headline (only the timed headline leg + the isolated per-kernel pass: what the rocprofv3 passes "
-                         "run) | comma list of the legs beside the headline: single,other,f32,graph,ops,cpu,cfg3,post,full,dropin,knn")
+                         "run) | comma list of the legs beside the headline: single,other,f32,graph,ops,cpu,cfg3,service,post,full,dropin,knn,image")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, form the process group, print {n_gpus, ranks_seen, backend} and stop: checks the "
                          "N-rank launch without touching a GPU (CPU tests, with --backend gloo)")
     ap.add_argument("--cpu-reps", type=int, default=10, help="timed config[0] calls of the CPU baseline (config[1]: a third)")
     args = ap.parse_args()
-    all_legs = {"single", "other", "f32", "graph", "ops", "cpu", "cfg3", "post", "full", "dropin", "knn"}
+    all_legs = {"single", "other", "f32", "graph", "ops", "cpu", "cfg3", "service", "post", "full", "dropin", "knn", "image"}
     legs = all_legs if args.legs == "all" else (set() if args.legs == "headline" else set(args.legs.split(",")))
     if not legs <= all_legs:
         raise SystemExit("--legs: unknown leg in %r" % (args.legs,))
@@ -601,6 +601,45 @@ def main():
         del sets3
         log("config[3] leg done: %.3f ms/step on %d streams, %.3f ms/forward on one" % (e3m / k3s * 1e3, len(streams),
                                                                                         extra["config3_n50000"]["single_stream_ms_per_forward"]))
+    if world == 1 and "service" in legs:
+        # the fork's own operating points (round-4 VERDICT item 2): its ROS services / demos sample ONE far larger cloud per
+        # call -- demo.py:836 40 000, demo_pointcloud.py:31 / foundationstereo.py:55 85 000, grasp_service.py:289 95 000 points
+        # (B = 1) -- so what they see is the latency of one forward + pred_decode: hipGraph replay, the SA1 sampler's share
+        # (2047 serial steps on ONE CU) and its us per step beside it
+        svc = {}
+        for n_s in (20000, 40000, 85000, 95000):
+            try:
+                x = S.make_batch(5000 + n_s, 1, n_s, "uniform").to(dev)
+                gnet = GraphedGraspNet(net, batch=1, points=n_s)
+                for _ in range(3):
+                    gnet(x)
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ts = []
+                for _ in range(15):
+                    a.record()
+                    gnet(x)
+                    b.record()
+                    b.synchronize()
+                    ts.append(a.elapsed_time(b))
+                del gnet
+                net.timing = {}
+                for _ in range(4):
+                    net.decode_padded(net({"point_clouds": x}))
+                torch.cuda.synchronize()
+                st_s = averages(net.timing)
+                net.timing = None
+                fps_ms = st_s.get("furthest_point_sampling[1]") or 0.0
+                svc[str(n_s)] = {"hipgraph_ms": statistics.median(ts), "eager_kernel_sum_ms": sum(st_s.values()),
+                                 "fps_sa1_ms": fps_ms, "fps_sa1_us_per_iteration": fps_ms * 1e3 / 2047.0,
+                                 "kernel_ms_top": {k: round(v, 4) for k, v in sorted(st_s.items(), key=lambda kv: -kv[1])[:4]}}
+            except Exception as ex:          # a leg beside the headline never takes the line down
+                svc[str(n_s)] = {"error": str(ex)[:200]}
+        extra["service_latency_ms"] = {k: v.get("hipgraph_ms") for k, v in svc.items()}
+        extra["service_latency"] = {"workload": "one cloud per call (B = 1), forward + pred_decode as one hipGraph replay incl. the "
+                                                "copy of the cloud into the graph's input; `uniform` synthetic clouds of the sizes the "
+                                                "fork's callers sample", "per_size": svc}
+        log("service-latency leg done: %s" % extra["service_latency_ms"])
     if world == 1 and "post" in legs:
         extra["postprocess"] = postprocess_leg(net, sets[0], dev)
         log("postprocess leg done")

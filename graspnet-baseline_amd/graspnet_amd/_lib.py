@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("GN_LIB_PATH") or os.path.join(_ROOT, "lib", "libgrasp
 CSRC = os.path.join(_ROOT, "csrc")
 
 _lib = None
+ABI_VERSION = 3          # include/graspnet_hip.h: GN_ABI_VERSION
 
 _c_int, _c_float, _c_void_p, _c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 
@@ -47,6 +48,8 @@ STAGE_HOOK = ctypes.CFUNCTYPE(None, ctypes.c_char_p, _c_int, _c_void_p)   # gn_s
 SIGNATURES = {
     "gn_last_error": (ctypes.c_char_p, []),
     "gn_version": (ctypes.c_char_p, []),
+    "gn_abi_version": (_c_int, []),
+    "gn_stream_capture_id": (_c_int, [_c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
     "gn_fps_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
     "gn_fps_prefix_check": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p,
                                      _c_void_p]),
@@ -173,6 +176,9 @@ def lib():
             fn = getattr(l, name)          # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
+        if l.gn_abi_version() != ABI_VERSION:
+            raise ImportError("%s has ABI revision %d, this package binds revision %d (include/graspnet_hip.h: GN_ABI_VERSION): "
+                              "rebuild it" % (LIB_PATH, l.gn_abi_version(), ABI_VERSION))
         _lib = l
     return _lib
 
@@ -181,6 +187,13 @@ def check(status, what):
     if status != 0:
         msg = lib().gn_last_error().decode("utf-8", "replace")
         raise RuntimeError("%s failed (gn_status %d): %s" % (what, status, msg))
+
+
+def capture_id(stream):
+    """0 when `stream` (the void* the C ABI takes) is not being captured into a hipGraph, else the capture's unique id."""
+    cid = ctypes.c_ulonglong(0)
+    check(lib().gn_stream_capture_id(stream, ctypes.byref(cid)), "stream_capture_id")
+    return int(cid.value)
 
 
 def ptr(t):

@@ -9,6 +9,8 @@ from . import knn_ext, pointnet2_ext
 
 
 def install():
+    pointnet2_ext.clear_grid_cache()       # a fresh installation starts without remembered clouds / sampling calls
+    pointnet2_ext.clear_fps_chain()
     pkg = sys.modules.get("pointnet2")
     if pkg is None:
         pkg = types.ModuleType("pointnet2")

@@ -99,6 +99,24 @@ class GraspNet:
         self._build()
         return self
 
+    def load_checkpoint(self, path, strict=True):
+        """What every caller of the reference does with a checkpoint file (test.py:57-58, demo.py:429, demo_pointcloud.py:47-49,
+        zividtest.py:88-98): `torch.load(path)['model_state_dict']` -> load_state_dict, here with a loader that executes
+        nothing from the file (`weights_only=True`) and onto the CPU first (the fold / packing of weights.py runs in float64 on
+        the host).  Accepts the dict train.py:211-219 saves ({'epoch', 'optimizer_state_dict', 'loss', 'model_state_dict'}),
+        a bare state-dict, and keys carrying the `module.` prefix of an nn.DataParallel model (train.py:215-218,
+        zividtest.py:93-97).  Returns the checkpoint's epoch (None if it holds none), like the callers print it."""
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        if not isinstance(ckpt, dict):
+            raise RuntimeError("load_checkpoint: %s does not hold a dict" % path)
+        sd = ckpt.get("model_state_dict", ckpt)
+        if not isinstance(sd, dict) or not all(torch.is_tensor(v) for v in sd.values()):
+            raise RuntimeError("load_checkpoint: %s holds no state-dict ('model_state_dict' or a bare one)" % path)
+        if sd and all(k.startswith("module.") for k in sd):
+            sd = {k[len("module."):]: v for k, v in sd.items()}
+        self.load_state_dict(sd, strict=strict)
+        return ckpt.get("epoch") if sd is not ckpt else None
+
     def state_dict(self):
         return dict(self._sd or {})
 
@@ -574,6 +592,14 @@ class PipelinedGraspNet:
 
 
 _NO_HOOK = L.STAGE_HOOK()      # NULL function pointer
+
+
+def load_checkpoint(path, device="cuda", **model_kwargs):
+    """get_net() of the reference's callers in one line (demo_pointcloud.py:40-53): build the model, load the checkpoint file
+    (GraspNet.load_checkpoint), eval mode.  -> (net, epoch)"""
+    net = GraspNet(is_training=False, device=device, **model_kwargs)
+    epoch = net.load_checkpoint(path)
+    return net.eval(), epoch
 
 
 def _expected_keys():

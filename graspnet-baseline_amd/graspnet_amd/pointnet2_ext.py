@@ -55,8 +55,14 @@ def _use_grid(n, m, nsample, radius):
 # tensor keeps the allocator from handing its memory to anyone else) on the same stream reuses it.  The query kernels take
 # any cell size (a grid built for a smaller reach only widens their cell window), so the first query's radius decides it,
 # exactly as in the fused path (one grid at SA1's radius for the ball query and the cylinder queries).  GN_GRID_CACHE=0
-# turns it off.  Memory written behind torch's back (a raw kernel on xyz's pointer) is not seen: inputs are borrowed,
-# never modified, on both sides of this boundary.
+# turns it off.  Memory written behind torch's back (a raw kernel on xyz's pointer, a write through `.data`) is not seen:
+# inputs are borrowed, never modified, on both sides of this boundary -- a caller that does rewrite a cloud in place that way
+# calls clear_grid_cache() (or sets GN_GRID_CACHE=0).
+# hipGraph capture: an entry also carries the id of the capture it was enqueued in (0 = eagerly; gn_stream_capture_id) and is
+# only reused while THAT capture is running (or, for id 0, outside any capture).  A grid built eagerly during warm-up is thus
+# never reused inside a capture on the same stream -- the build would be missing from the graph and its replays would read the
+# warm-up cloud's cells -- and a grid built inside a capture (its buffer lives in the graph's memory pool, the build is part
+# of the graph) serves the later queries of the same capture, as it does eagerly: one build per captured forward.
 _GRID_CACHE = {}
 
 
@@ -65,17 +71,18 @@ def _grid_for(lib, xyz, b, n, reach, st, what):
     dev = xyz.device
     key = (dev.index, int(st or 0))
     use = os.environ.get("GN_GRID_CACHE", "1") != "0"
+    cap = L.capture_id(st) if use else 0
     hit = _GRID_CACHE.get(key) if use else None
     if hit is not None:
-        src, ver, grid, built = hit
+        src, ver, grid, built, hit_cap = hit
         # (a grid built for a very different reach stays correct but walks many small / few huge cells: rebuild then)
-        if (src.data_ptr() == xyz.data_ptr() and src.shape == xyz.shape and src._version == ver and xyz._version == ver
-                and 0.25 * reach <= built <= 1.5 * reach):
+        if (hit_cap == cap and src.data_ptr() == xyz.data_ptr() and src.shape == xyz.shape and src._version == ver
+                and xyz._version == ver and 0.25 * reach <= built <= 1.5 * reach):
             return grid
     grid = torch.empty((lib.gn_grid_workspace_bytes(b, n),), dtype=torch.uint8, device=dev)
     L.check(lib.gn_grid_build(xyz.data_ptr(), b, n, float(reach), grid.data_ptr(), st), what + " (grid build)")
     if use:
-        _GRID_CACHE[key] = (xyz, xyz._version, grid, float(reach))
+        _GRID_CACHE[key] = (xyz, xyz._version, grid, float(reach), cap)
     return grid
 
 
@@ -113,7 +120,9 @@ def _dispatch(first, others):
 # (device, stream) is remembered -- its input, its indices, its tie step, with the tensors' version counters -- and a later call
 # whose input is bit for bit the points that call picked (gn_fps_prefix_check, one small launch) inherits the tie step as the
 # kernel's `prefix_ok`: the identity prefix is written at once, or the chain warm-starts behind the tie.  An input that is
-# anything else gets no promise and runs in full.  GN_FPS_CHAIN=0 turns it off.
+# anything else gets no promise and runs in full.  GN_FPS_CHAIN=0 turns it off.  Like the grid cache, a remembered call is
+# only consulted inside the hipGraph capture it was enqueued in (or eagerly, if it was enqueued eagerly): a captured
+# gn_fps_prefix_check would otherwise read, on every replay, tensors of a warm-up call that the allocator is free to reuse.
 _FPS_LAST = {}
 
 
@@ -132,11 +141,12 @@ def furthest_point_sampling(points, nsamples):
     tie = torch.empty((b,), dtype=torch.int32, device=dev) if chain else None
     prefix = None
     with torch.cuda.device(dev):
+        cap = L.capture_id(st) if chain else 0
         last = _FPS_LAST.get(key) if chain else None
         if last is not None:
-            src, src_ver, inds, inds_ver, t1 = last
-            if (src.size(0) == b and inds.size(1) >= n and src._version == src_ver and inds._version == inds_ver
-                    and src.data_ptr() != points.data_ptr()):
+            src, src_ver, inds, inds_ver, t1, last_cap = last
+            if (last_cap == cap and src.size(0) == b and inds.size(1) >= n and src._version == src_ver
+                    and inds._version == inds_ver and src.data_ptr() != points.data_ptr()):
                 prefix = torch.empty((b,), dtype=torch.int32, device=dev)
                 L.check(lib.gn_fps_prefix_check(points.data_ptr(), src.data_ptr(), inds.data_ptr(), t1.data_ptr(), b, n,
                                                 src.size(1), inds.size(1), prefix.data_ptr(), st), "fps_prefix_check")
@@ -146,7 +156,7 @@ def furthest_point_sampling(points, nsamples):
     if chain:
         # a call that ran on a promise passes the promise on (its own kernel does not track ties); one that did not reports
         # its own tie step (0 = "unknown" from kernels that do not track it: no promise for the next link)
-        _FPS_LAST[key] = (points, points._version, out, out._version, prefix if prefix is not None else tie)
+        _FPS_LAST[key] = (points, points._version, out, out._version, prefix if prefix is not None else tie, cap)
     return out
 
 

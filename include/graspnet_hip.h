@@ -44,8 +44,19 @@ typedef enum gn_status {
 
 /* Human-readable text for the last error on this thread ("" if none). */
 const char *gn_last_error(void);
-/* Library / build identification, e.g. "graspnet_hip 0.1 gfx950". */
+/* Library / build identification, e.g. "graspnet_hip 0.5 gfx950". */
 const char *gn_version(void);
+/* Binary interface revision: bumped whenever an existing entry point changes its parameter list or a parameter's type
+ * (revision 2: `voxel_size` of gn_collision_detect / gn_collision_detect_batched became a double; revision 3: the
+ * evaluation-policy entry gn_set_fp_policy, gn_stream_capture_id, voxel_status of gn_grasp_postprocess reported).  A host
+ * built against this header checks  gn_abi_version() == GN_ABI_VERSION  once after loading the library. */
+#define GN_ABI_VERSION 3
+int gn_abi_version(void);
+/* *id = 0 when `stream` is not being captured into a hipGraph, else the running capture's unique id (> 0).  For host-side
+ * caches of device buffers (graspnet_amd/pointnet2_ext.py keeps the last grid / sampling call per stream): an entry enqueued
+ * outside a capture must not be reused inside one (the work that fills it would be missing from the graph), and one enqueued
+ * inside a capture only inside that same capture. */
+int gn_stream_capture_id(gn_stream_t stream, unsigned long long *id);
 
 /* ------------------------------------------------------------------ *
  *  pointnet2._ext operators                                          *

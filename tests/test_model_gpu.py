@@ -326,6 +326,14 @@ def test_against_golden_samples(hip, golden_dir):
     ("config[1] on surface clouds (duplicates, FPS ties)", 8, 20000, "surface", 1000),
     ("config[3]: dense 50000-pt cloud, full forward (B=1)", 1, 50000, "uniform", 1000),
     ("config[3] at the bench leg's batch: 8 x 50000-pt clouds", 8, 50000, "uniform", 3000),
+    # the fork's OWN operating points above the operator boundary (round-4 VERDICT missing item 2): its callers sample far
+    # larger single clouds than BASELINE's configurations -- fps_cell.hip's S = 32 region layout (> 65 536 points), the grid's
+    # cell counts and every workspace size at model level
+    ("fork caller demo.py:836 (--num_point 40000): one 40000-pt cloud", 1, 40000, "uniform", 5000),
+    ("fork caller grasp_segmentation.py:539 (45000): one 45000-pt surface cloud", 1, 45000, "surface", 5003),
+    ("fork callers demo_pointcloud.py:31 / foundationstereo.py:55 (85000): one 85000-pt surface cloud", 1, 85000, "surface", 5001),
+    ("fork caller grasp_service.py:289 (95000): one 95000-pt cloud", 1, 95000, "uniform", 5002),
+    ("fork caller grasp_service.py:289 (95000): two 95000-pt surface clouds", 2, 95000, "surface", 5004),
 ])
 def test_baseline_configs_at_their_own_size(net, model_oracle, state_dict, name, B, N, variant, seed):
     """BASELINE.json's configurations at their own batch and cloud size on the HIP path, against the oracle (fp32 and

@@ -229,6 +229,29 @@ def test_fps_warm_start_behind_a_tie(oracle):
         level = nx
 
 
+@pytest.mark.parametrize("n,variant", [(95000, "uniform"), (85000, "surface"), (95000, "surface")])
+def test_operators_at_the_forks_own_cloud_sizes(E, oracle, model_oracle, n, variant):
+    """grasp_service.py:289 samples 95 000 points, demo_pointcloud.py:31 / foundationstereo.py:55 85 000 (B = 1): the FULL-length
+    SA1 sampler (2048 samples: fps_cell.hip's 32 x 32 regions), SA1's ball query and CloudCrop's four cylinder queries at
+    that size, bit-exact against the oracle through the drop-in operators (grid path)"""
+    x = _cloud(8000 + n, 1, n, variant)
+    xd = _dev(x)
+    inds = E.furthest_point_sampling(xd, 2048).cpu()
+    assert torch.equal(inds, oracle.furthest_point_sampling(x, 2048))
+    c = torch.gather(x, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    assert torch.equal(E.ball_query(_dev(c), xd, 0.04, 64).cpu(), oracle.ball_query(c, x, 0.04, 64))
+    seeds = c[:, :1024].contiguous()
+    rng = np.random.default_rng(n)
+    rot = model_oracle.viewpoint_to_matrix(torch.from_numpy(rng.standard_normal((1024, 3)).astype(np.float32)),
+                                           torch.zeros(1024)).view(1, 1024, 9).contiguous()
+    for hmax in (0.01, 0.02, 0.03, 0.04):
+        got = E.cylinder_query(_dev(seeds), xd, _dev(rot), 0.05, -0.02, hmax, 64).cpu()
+        assert torch.equal(got, oracle.cylinder_query(seeds, x, rot, 0.05, -0.02, hmax, 64)), hmax
+    f = x.transpose(1, 2).contiguous()
+    idx = oracle.ball_query(c, x, 0.04, 64)
+    assert torch.equal(E.group_points(_dev(f), _dev(idx)).cpu(), oracle.group_points(f, idx))
+
+
 SA = [(20000, 2048, 0.04, 64), (2048, 1024, 0.1, 32), (1024, 512, 0.2, 16), (512, 256, 0.3, 16)]
 
 

@@ -462,6 +462,9 @@ def main():
 
     def run_steps(model, batches, strms, nsteps, gather=True, post=False):
         last = None
+        # several batches in flight: the per-point chains in their throughput tile shapes (fewer CU-microseconds per launch;
+        # GraspNet.throughput / gn_set_point_tile_policy -- what PipelinedGraspNet does); one stream: the latency shapes
+        model.throughput = len(strms) > 1 and os.environ.get("GN_POINT_TILES", "auto") != "latency"
         for i in range(nsteps):
             with torch.cuda.stream(strms[i % len(strms)]):
                 ep = model({"point_clouds": batches[i % len(batches)]})

@@ -6,23 +6,9 @@
 // a barrier retires the input, and the epilogue writes relu(y) -- split again -- over it.  All layers run in the T
 // orientation (A = weights, B = activations): a lane ends up with 4 consecutive channels of its position per register
 // quad, i.e. one 8-byte LDS store per plane, or 4 consecutive floats of an output row.
-#include "mlp_split.h"
+#include "mlp_point_stream.h"
 
 namespace gn {
-
-struct PointSplitArgs {
-  const void *w[3];
-  const float *b[3];
-  const float *x;       // plain loader: (rows, C0) channels-last
-  const float *known;   // fp loader: (B, m, CK) features to interpolate
-  const float *skip;    //            (B, n, CS) skip features
-  const float *dist2;   //            (B, n, 3)
-  const int32_t *idx3;  //            (B, n, 3)
-  int n, m;
-  float *out;           // (rows, ldo)
-  int ldo, ncols_out;
-  int nrows;
-};
 
 __device__ __forceinline__ void store_split4(__bf16 *row, int plane, const f32x4 &v) {
   u32x2 hi, mid, lo;
@@ -117,95 +103,6 @@ __device__ __forceinline__ void load_fp_split(__bf16 *__restrict__ ys, int plane
       store_split4(ys + r * XS + CK + c4 * 4, plane, v[u]);
     }
   }
-}
-
-// One streamed layer, T orientation.  MFMA phase: every (M tile, n-tile) of this wave accumulates over all K with the
-// weight chunks double-buffered; then `retire()` (a workgroup barrier when the output overwrites the input) and the
-// epilogue epi(mt, nt, acc) per tile.
-// bias of the 16 accumulator rows of n-tile nt (T orientation: rows = channels 8g + 4*(lane>>5) + j): four 16-byte loads,
-// issued when the layer starts and consumed by its epilogue, so their L2 round trip hides under the layer's MFMAs
-__device__ __forceinline__ void load_bias_t4(const float *__restrict__ bp, int nt, int lane, f32x4 (&bt)[4]) {
-  using gf4 = const __attribute__((address_space(1))) f32x4;     // global, not flat: see StreamChunk::load
-  const __attribute__((address_space(1))) float *gb = (const __attribute__((address_space(1))) float *)bp;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) bt[g] = *(gf4 *)(gb + nt * 32 + 8 * g + 4 * (lane >> 5));
-}
-
-// shape of a streamed layer for this kernel family.  CHREG: registers one weight chunk may take per wave (96 with one
-// workgroup per CU, 48 with two -- a wave then has 256 registers, 64-96 of them accumulators)
-template <int TP, int CINP, int COUTP, int CHREG = 96>
-struct StreamCfg {
-  static_assert(CINP % 32 == 0 && COUTP % 32 == 0, "K in chunks of at least 32");
-  static constexpr int NT = COUTP / 32, MT = TP / 32, WN = wn_for(COUTP);
-  static constexpr int WM = (4 / WN < MT) ? 4 / WN : MT;      // a 32-row tile of a 64-wide layer occupies two waves only
-  static constexpr int NACTIVE = WN * WM, NTW = NT / WN;
-  static_assert(NT % WN == 0 && MT % WM == 0, "tiles must divide over the waves");
-  // k-blocks per weight chunk: at least ~48 MFMAs behind every chunk load (an L2 round trip) where the registers allow,
-  // so small layers take longer chunks
-  static constexpr int MTW = MT / WM, KB = CINP / 16;
-  static constexpr int KBC0 = (MTW * NTW >= 4) ? 2 : (MTW * NTW >= 2 ? 4 : 8);
-  static constexpr int KBC1 = (NTW * KBC0 * 12 <= CHREG) ? KBC0 : (NTW * (KBC0 / 2) * 12 <= CHREG || KBC0 / 2 <= 1 ? cmax(KBC0 / 2, 1)
-                                                                                                                   : cmax(KBC0 / 4, 1));
-  static constexpr int KBC = (KB % KBC1 == 0) ? KBC1 : (KBC1 > 2 ? 2 : 1);
-  static constexpr int NCH = KB / KBC;
-  static_assert(KB % KBC == 0, "K must be a multiple of the chunk");
-};
-
-// one chunk of this wave's split weight fragments in registers
-template <int TP, int CINP, int COUTP, int CHREG>
-struct StreamChunk {
-  using C = StreamCfg<TP, CINP, COUTP, CHREG>;
-  bf16x8 v[C::NTW][C::KBC][3];
-  // The weights are addressed as GLOBAL memory explicitly.  Behind the `asm` that pins a layer's pointer below its barrier
-  // the compiler no longer knows the address space and emitted flat_load -- which counts on lgkmcnt as well as vmcnt, so
-  // the first s_waitcnt lgkmcnt(0) for an LDS operand of the CURRENT chunk also waited for the NEXT chunk's weights: the
-  // double buffering never overlapped anything (58 / 75 / 91 cycles per MFMA in the heads' layers against 34 bare).
-  __device__ __forceinline__ void load(const void *__restrict__ wq, int c, int wave, int lane) {
-    const int wn = wave % C::WN;
-    using gchar = const __attribute__((address_space(1))) char;
-    using gfrag = const __attribute__((address_space(1))) bf16x8;
-    gchar *wbase = (gchar *)wq;
-#pragma unroll
-    for (int i = 0; i < C::NTW; ++i)
-#pragma unroll
-      for (int kb = 0; kb < C::KBC; ++kb)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          v[i][kb][p] = *(gfrag *)(wbase + ((((size_t)((wn * C::NTW + i) * C::KB + c * C::KBC + kb)) * 3 + p) * 64 + lane) * 16);
-  }
-  // called where the chunk is consumed (its data is needed there anyway; at the load an asm operand would force the
-  // wait and undo the double buffering): from here on the fragments live in AGPRs and the MFMAs read them from there
-  // (mlp_split.h LayerWS::load), so the VGPRs stay free for the two accumulators per tile
-  __device__ __forceinline__ void pin() {
-#pragma unroll
-    for (int i = 0; i < C::NTW; ++i)
-#pragma unroll
-      for (int kb = 0; kb < C::KBC; ++kb)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) asm volatile("" : "+a"(v[i][kb][p]));
-  }
-};
-
-// Every layer used to start with an L2 round trip for its first weight chunk (~2.5 k cycles with nothing else to do: the
-// phase probe shows 58 / 75 / 91 cycles per MFMA in the heads' three layers against 34 bare).  The first chunk of layer
-// L+1 is now requested by layer L just before its epilogue -- its own chunk buffers are dead by then, so the registers are
-// there -- and lands under the epilogue and the barrier behind it; layer 1's is requested at the tile top, under the row
-// fetch.  (Requesting it any earlier, while layer L still streams, keeps three layers' buffers live and spills.)
-// BLOCK2: the layer is two independent halves side by side (OperationNet | ToleranceNet, modules.py:171-175,216-220, packed
-// as ONE block-diagonal matrix): output channels of the first half read only the first half of K, the others only the
-// second, and the other K chunks of a wave's weight slice are all zeros -- they are not streamed and not multiplied.
-// first chunk of a (BLOCK2) layer for this wave
-template <int TP, int CINP, int COUTP, int CHREG, bool BLOCK2>
-__device__ __forceinline__ int stream_first_chunk(int wave) {
-  using C = StreamCfg<TP, CINP, COUTP, CHREG>;
-  return BLOCK2 ? ((wave % C::WN) >= C::WN / 2 ? C::NCH / 2 : 0) : 0;
-}
-// request the first chunk of a layer (no-op for the waves the layer leaves idle)
-template <int TP, int CINP, int COUTP, int CHREG, bool BLOCK2>
-__device__ __forceinline__ void stream_prefetch(StreamChunk<TP, CINP, COUTP, CHREG> &ch, const void *__restrict__ wq, int wave, int lane) {
-  using C = StreamCfg<TP, CINP, COUTP, CHREG>;
-  if (C::NACTIVE < 4 && wave >= C::NACTIVE) return;
-  ch.load(wq, stream_first_chunk<TP, CINP, COUTP, CHREG, BLOCK2>(wave), wave, lane);
 }
 
 // `first` arrives with the layer's first chunk already requested (stream_prefetch); `pre()` requests the next layer's
@@ -407,6 +304,27 @@ using namespace gn;
 // is as long as the MFMAs) while ApproachNet gains a little (52.9 -> 49.6 us: its 128 64-row tiles fill half the chip,
 // 256 32-row tiles all of it).  Default: 2 for ApproachNet only.  GN_POINT_WPC=1 / 2 forces one shape for both (read
 // per call so that a test can A/B them).
+namespace gn {
+static thread_local int g_point_tile_policy = 0;
+int point_tile_policy() {
+  const char *e = getenv("GN_POINT_TILES");      // read per call: tests and profiles A/B the shapes in one process
+  if (e) return (e[0] == 't' || e[0] == '1') ? 1 : 0;
+  return g_point_tile_policy;
+}
+}  // namespace gn
+
+extern "C" int gn_set_point_tile_policy(int policy) {
+  const int prev = gn::g_point_tile_policy;
+  gn::g_point_tile_policy = policy ? 1 : 0;
+  return prev;
+}
+
+// GN_POINT_WIDE=0 / 1 forces the plane / fp32-tile form of every chain (tests); otherwise the policy decides
+static int wide_forced() {
+  const char *we = getenv("GN_POINT_WIDE");
+  return we ? (atoi(we) != 0 ? 1 : 0) : -1;
+}
+
 static int point_wpc(int dflt) {
   const char *e = getenv("GN_POINT_WPC");
   return e ? atoi(e) : dflt;
@@ -426,6 +344,10 @@ extern "C" int gn_fp_interp_mlp_split(const float *known_feat, const float *skip
   a.w[0] = wpacked[0]; a.b[0] = bias[0]; a.w[1] = wpacked[1]; a.b[1] = bias[1];
   a.known = known_feat; a.skip = skip_feat; a.dist2 = dist2; a.idx3 = idx3; a.n = n; a.m = m;
   a.out = out; a.ldo = 256; a.ncols_out = 256; a.nrows = b * n;
+  {
+    const int wf = wide_forced();
+    if (wf == 1 || (wf < 0 && point_tile_policy() == 1)) return fp_mlp_wide(a, as_stream(stream));
+  }
   return launch_point_split<PLOAD_FP, 2, 512, 256, 256, 256, 0, 0, 32, true>(a, as_stream(stream), "fp_interp_mlp_split");
 }
 
@@ -441,6 +363,14 @@ extern "C" int gn_approach_mlp_split(const float *x, int rows, int cin, int nout
   PointSplitArgs a{};
   for (int i = 0; i < 3; ++i) { a.w[i] = wpacked[i]; a.b[i] = bias[i]; }
   a.x = x; a.out = out; a.ldo = nout; a.ncols_out = nout; a.nrows = rows;
+  {
+    const int wf = wide_forced();
+    // 64-row fp32 tiles under either policy: measured at batch 8 (profiles/point_chain_bench.py) 46.7 us on 128 CUs against
+    // 49.0 us on 256 for the 32-row plane tiles; a launch too small to give 64 CUs a tile keeps the 32-row form under the
+    // latency policy
+    if (wf == 1 || (wf < 0 && !getenv("GN_POINT_WPC") && (point_tile_policy() == 1 || rows >= 64 * 64)))
+      return approach_mlp_wide(a, as_stream(stream));
+  }
   if (point_wpc(2) >= 2)
     return launch_point_split<PLOAD_PLAIN, 3, 256, 256, 256, 384, 320, 384, 32, false, 2>(a, as_stream(stream), "approach_mlp_split");
   return launch_point_split<PLOAD_PLAIN, 3, 256, 256, 256, 384, 320, 384, 64, false>(a, as_stream(stream), "approach_mlp_split");
@@ -462,6 +392,13 @@ extern "C" int gn_heads_mlp_split(const float *x, int rows, int cin, int nout, c
   // GN_HEADS_DENSE=1 multiplies the zero blocks too (the round-1 form; A/B in tests/test_split_gpu.py)
   const char *de = getenv("GN_HEADS_DENSE");
   const bool dense = de && atoi(de) != 0;
+  // enough rows to give (nearly) every CU a 128-row tile (or the throughput policy): the wide form streams a layer's weights
+  // once per 128 rows instead of once per 64 (mlp_point_wide.hip; bit-identical outputs: tests/test_split_gpu.py)
+  {
+    const int wf = wide_forced();
+    if (wf == 1 || (wf < 0 && !dense && !getenv("GN_POINT_WPC") && (rows >= 128 * 192 || point_tile_policy() == 1)))
+      return heads_mlp_wide(a, as_stream(stream));
+  }
   if (point_wpc(1) >= 2) {
     if (dense) return launch_point_split<PLOAD_PLAIN, 3, 256, 256, 256, 256, 256, 64, 32, false, 2>(a, as_stream(stream), "heads_mlp_split");
     return launch_point_split<PLOAD_PLAIN, 3, 256, 256, 256, 256, 256, 64, 32, false, 2, true>(a, as_stream(stream), "heads_mlp_split");

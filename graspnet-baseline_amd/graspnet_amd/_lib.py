@@ -114,6 +114,7 @@ SIGNATURES = {
                                        ctypes.POINTER(_c_void_p), _c_void_p, _c_void_p]),
     "gn_heads_mlp_split": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
                                     _c_void_p, _c_void_p]),
+    "gn_set_point_tile_policy": (_c_int, [_c_int]),
     "gn_point_linear_split": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "gn_approach_mlp": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_void_p),
                                  _c_void_p, _c_void_p]),

@@ -58,6 +58,11 @@ class GraspNet:
         # (gn_outputs.fork_streams).  A steady gain only inside a captured hipGraph (GraphedGraspNet sets it while it
         # captures); between eagerly issued streams it depends on the hardware-queue mapping, so the default is off
         self.fork = False
+        # Tile shapes of the per-point chains (FP, ApproachNet, heads; include/graspnet_hip.h gn_set_point_tile_policy).  False:
+        # every launch spreads over as many CUs as it can -- the shortest launch for ONE batch at a time.  True: 64- / 128-row
+        # fp32 tiles (csrc/mlp_point_wide.hip) that stream the weights once per 64 / 128 rows on half as many CUs: a third fewer
+        # CU-microseconds per batch, which other batches in flight use (PipelinedGraspNet sets it).  Outputs are bit-identical.
+        self.throughput = os.environ.get("GN_POINT_TILES", "latency").startswith("t")
         # CloudCrop over de-duplicated (seed, point) rows (default) or over the four full index lists
         self.crop_unique = os.environ.get("GN_CROP_PATH", "unique") != "lists"
         # SA2-4: layer 1's per-point part hoisted out of the per-neighbour MLP (bit-identical, fewer MFMAs)
@@ -263,6 +268,7 @@ class GraspNet:
         if pc.dtype != torch.float32 or pc.dim() != 3 or pc.size(-1) < 3:
             raise RuntimeError("point_clouds must be a (B,N,3) float tensor")
         lib = L.lib()
+        lib.gn_set_point_tile_policy(1 if self.throughput else 0)
         dev = pc.device
         B, N = pc.size(0), pc.size(1)
         f32, i32 = torch.float32, torch.int32
@@ -562,11 +568,13 @@ class PipelinedGraspNet:
             self._register(torch.cuda.current_stream(self.grasps.device))
             return self.end_points, self.grasps, self.counts
 
-    def __init__(self, net, depth=12, post=None):
+    def __init__(self, net, depth=12, post=None, throughput_tiles=True):
         """post: None, or a dict of postprocess.grasp_pipeline() keyword arguments: every submitted batch then also goes through
         the collision filter + sort + NMS on its stream (no host read), and the ticket carries `final_rows` (B,M,17), `kept` (B,)
-        and `collision_mask` (B,M) beside the raw grasps."""
+        and `collision_mask` (B,M) beside the raw grasps.
+        throughput_tiles: run the per-point chains in their throughput tile shapes (GraspNet.throughput) while submitting."""
         self.net = net
+        self.throughput_tiles = bool(throughput_tiles) and int(depth) > 1
         self.post = None if post is None else dict(post)
         self.streams = [torch.cuda.Stream(device=net.device) for _ in range(max(1, int(depth)))]
         self._i = 0
@@ -576,7 +584,11 @@ class PipelinedGraspNet:
         self._i += 1
         st.wait_stream(torch.cuda.current_stream(point_clouds.device))     # the input may still be in flight there
         with torch.cuda.stream(st):
-            ep = self.net({"point_clouds": point_clouds})
+            keep, self.net.throughput = self.net.throughput, (self.net.throughput or self.throughput_tiles)
+            try:
+                ep = self.net({"point_clouds": point_clouds})
+            finally:
+                self.net.throughput = keep
             grasps, counts = self.net.decode_padded(ep)
             tail = None
             if self.post is not None:

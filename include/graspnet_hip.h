@@ -285,6 +285,14 @@ int gn_heads_mlp_split(const float *x, int rows, int cin, int nout, const void *
 int gn_point_linear_split(const float *x, int rows, int cin, int cout, const void *wpacked, const float *bias, float *out,
                           gn_stream_t stream);
 
+/* Tile shapes of the per-point chains above (per calling thread; returns the previous setting):
+ *   0 (default) "latency": every launch spreads over as many CUs as it has 32-row tiles -- the shortest launch when nothing runs
+ *     beside it (one batch at a time, hipGraph replay);
+ *   1 "throughput": 64-row fp32 tiles for ApproachNet / feature propagation and 128-row tiles for the heads (csrc/
+ *     mlp_point_wide.hip: half / a quarter of the weight bytes per row, half as many workgroups) -- fewer CU-microseconds per
+ *     launch, for callers that keep several batches in flight on several streams.  Outputs are bit-identical either way. */
+int gn_set_point_tile_policy(int policy);
+
 /* ApproachNet conv1/bn1/relu, conv2/bn2/relu, conv3 (models/modules.py:55-57):
  * x (rows,256) -> out (rows, nout = 2+num_view) = [objectness | view scores], 3 <= nout <= 320; the packed layers are
  * 256 -> 256 -> 384 -> 384 whatever nout is (layer 3's K padded to 320; zeros beyond nout). */

@@ -85,3 +85,26 @@ for name, out, fn in cases:
     print("%-50s wpc1 %7.1f us   wpc2 %7.1f us   outputs %s" % (name, res["1"][1], res["2"][1], "identical" if same else
           "DIFFER max %.3e" % float((res["1"][0] - res["2"][0]).abs().max())), flush=True)
 print("sum: wpc1 %.1f us, wpc2 %.1f us" % (tot["1"], tot["2"]))
+# every chain in its plane form (latency shapes) against its fp32-tile form (mlp_point_wide.hip: heads 128-row, ApproachNet /
+# FP 64-row tiles): launch time and launch time x CUs the grid occupies (what a launch costs other batches in flight)
+del os.environ["GN_POINT_WPC"]; del os.environ["GN_LINEAR_WPC"]
+tiles = {"heads": (64, 128), "approach": (32, 64), "fp1": (32, 64), "fp2": (32, 64)}
+rows_of = {"heads": B * 4096, "approach": B * 1024, "fp1": B * 512, "fp2": B * 1024}
+tw = {"0": 0.0, "1": 0.0}
+cw = {"0": 0.0, "1": 0.0}
+for name, out, fn in cases[:4]:
+    key = name.split()[0]
+    res = {}
+    for wide in ("0", "1"):
+        os.environ["GN_POINT_WIDE"] = wide
+        out.zero_()
+        fn()
+        torch.cuda.synchronize()
+        res[wide] = (out.clone(), timed(fn))
+        wgs = min(256, -(-rows_of[key] // tiles[key][int(wide)]))
+        tw[wide] += res[wide][1]
+        cw[wide] += res[wide][1] * wgs
+    del os.environ["GN_POINT_WIDE"]
+    print("%-50s plane tiles %7.1f us   fp32 tiles %7.1f us   outputs %s" % (name, res["0"][1], res["1"][1],
+          "identical" if torch.equal(res["0"][0], res["1"][0]) else "DIFFER max %.3e" % float((res["0"][0] - res["1"][0]).abs().max())))
+print("sum of the four chains: plane %.1f us (%.0f CU-us), fp32 tiles %.1f us (%.0f CU-us)" % (tw["0"], cw["0"], tw["1"], cw["1"]))

@@ -189,11 +189,12 @@ def test_heads_and_approach_split_on_oracle_inputs(ref, truth, net):
     assert e_or[0] >= 0.0
 
 
-@pytest.mark.parametrize("rows", [8192, 1000, 33])
+@pytest.mark.parametrize("rows", [8192, 1000, 33, 32768, 4133])
 def test_point_chain_tile_shapes_are_bit_identical(net, monkeypatch, rows):
-    """the per-point chains in their two tile shapes (GN_POINT_WPC=1: 64-row tiles, one workgroup per CU; 2: 32-row tiles,
-    two per CU, idle waves in the 64-wide last layer of the heads): the k order of every dot product is the same, so the
-    outputs must be identical -- ragged last tiles included"""
+    """the per-point chains in their tile shapes (GN_POINT_WPC=1: 64-row tiles, one workgroup per CU; 2: 32-row tiles,
+    two per CU, idle waves in the 64-wide last layer of the heads; GN_POINT_WIDE=1: the heads on 128-row fp32 tiles split at
+    fragment load, mlp_point_wide.hip -- the default from 24 576 rows): the k order of every dot product and every bf16 cut
+    are the same, so the outputs must be identical -- ragged last tiles included"""
     from graspnet_amd import _lib as L
     lib = L.lib()
     st = torch.cuda.current_stream().cuda_stream
@@ -202,16 +203,46 @@ def test_point_chain_tile_shapes_are_bit_identical(net, monkeypatch, rows):
     for fn, pk, nout in ((lib.gn_heads_mlp_split, net._packed["heads_split"], 48),
                          (lib.gn_approach_mlp_split, net._packed["approach_split"], 302)):
         res = []
-        for wpc, dense in (("1", "0"), ("2", "0"), ("1", "1"), ("2", "1")):
+        for wpc, dense, wide in (("1", "0", "0"), ("2", "0", "0"), ("1", "1", "0"), ("2", "1", "0"), ("1", "0", "1")):
             # GN_HEADS_DENSE=1: the heads' block-diagonal layer 2 multiplies its zero blocks too (adds exact zeros)
             monkeypatch.setenv("GN_POINT_WPC", wpc)
             monkeypatch.setenv("GN_HEADS_DENSE", dense)
+            monkeypatch.setenv("GN_POINT_WIDE", wide)
             o = torch.full((rows + 1, nout), float("nan"), device="cuda")
             L.check(fn(x.data_ptr(), rows, 256, nout, pk.wptr, pk.bptr, o.data_ptr(), st), "chain")
             torch.cuda.synchronize()
             assert torch.isnan(o[rows]).all() and not torch.isnan(o[:rows]).any()     # nothing beyond the last row
             res.append(o[:rows])
         assert all(torch.equal(res[0], r) for r in res[1:])
+    monkeypatch.delenv("GN_POINT_WPC"); monkeypatch.delenv("GN_HEADS_DENSE"); monkeypatch.delenv("GN_POINT_WIDE")
+    # the feature-propagation chain (gathered + interpolated + skip rows, K = 512) on 32-row plane tiles against 64-row
+    # fp32 tiles, and the policy switch (gn_set_point_tile_policy / GN_POINT_TILES) that picks the forms
+    import ctypes
+    b, n, m = 2, max(rows // 2, 3), 17
+    known, skip = torch.randn(b, m, 256, generator=g).cuda(), torch.randn(b, n, 256, generator=g).cuda()
+    d2 = (torch.rand(b, n, 3, generator=g) * 0.01).cuda()
+    i3 = torch.randint(0, m, (b, n, 3), generator=g, dtype=torch.int32).cuda()
+    pk = net._packed["fp2_split"]
+    mlp = (ctypes.c_int * 2)(256, 256)
+    res = []
+    for tiles in ("latency", "throughput"):
+        monkeypatch.setenv("GN_POINT_TILES", tiles)
+        o = torch.full((b * n + 1, 256), float("nan"), device="cuda")
+        L.check(lib.gn_fp_interp_mlp_split(known.data_ptr(), skip.data_ptr(), d2.data_ptr(), i3.data_ptr(), b, n, m, 256, 256, mlp,
+                                           pk.wptr, pk.bptr, o.data_ptr(), st), "fp")
+        torch.cuda.synchronize()
+        assert torch.isnan(o[b * n]).all() and not torch.isnan(o[:b * n]).any()
+        res.append(o[:b * n])
+    assert torch.equal(res[0], res[1])
+    monkeypatch.delenv("GN_POINT_TILES")
+    prev = lib.gn_set_point_tile_policy(1)
+    try:
+        o = torch.empty((b * n, 256), device="cuda")
+        L.check(lib.gn_fp_interp_mlp_split(known.data_ptr(), skip.data_ptr(), d2.data_ptr(), i3.data_ptr(), b, n, m, 256, 256, mlp,
+                                           pk.wptr, pk.bptr, o.data_ptr(), st), "fp")
+        assert lib.gn_set_point_tile_policy(prev) == 1 and torch.equal(o, res[0])
+    finally:
+        lib.gn_set_point_tile_policy(0)
 
 
 def test_sa_split_equals_fp32_kernels_to_rounding(net, clouds):

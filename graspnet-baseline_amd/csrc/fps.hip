@@ -29,6 +29,7 @@
 #include "fps_util.h"
 
 namespace gn {
+namespace GN_FPNS {
 
 template <int NT, int PPT>
 __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ xyz, int n, int m,
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
       x = xyz[k * 3 + 0];
       y = xyz[k * 3 + 1];
       z = xyz[k * 3 + 2];
-      const float mag = (x * x) + (y * y) + (z * z);
+      const float mag = fp_sumsq3(x, y, z);
       // sampling_gpu.cu:105-106: `if (mag <= 1e-3) continue;` (float vs double literal).
       // A skipped point never updates temp and is never a candidate: temp = -1 does both.
       t0 = ((double)mag <= 1e-3) ? -1.0f : 1e10f;   // 1e10 = sampling.cpp:78-80
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
 #pragma unroll
         for (int s = 0; s < PPT; ++s) {
           const float dx = px[s] - sx, dy = py[s] - sy, dz = pz[s] - sz;
-          const float d = dx * dx + dy * dy + dz * dz;
+          const float d = fp_sumsq3(dx, dy, dz);
           tmp[s] = vmin(d, tmp[s]);
         }
       }
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
       const float dx = px[s] - x1, dy = py[s] - y1, dz = pz[s] - z1;
-      const float d = dx * dx + dy * dy + dz * dz;
+      const float d = fp_sumsq3(dx, dy, dz);
       const float d2 = vmin(d, tmp[s]);
       tmp[s] = d2;
       const bool gt = d2 > best;
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(1024) void fps_spatial_kernel(const float *__restri
     float x = 0.f, y = 0.f, z = 0.f, t0 = -1.0f;
     if (k >= 0) {
       x = xyz[k * 3 + 0]; y = xyz[k * 3 + 1]; z = xyz[k * 3 + 2];
-      const float mag = (x * x) + (y * y) + (z * z);
+      const float mag = fp_sumsq3(x, y, z);
       t0 = ((double)mag <= 1e-3) ? -1.0f : 1e10f;       // sampling_gpu.cu:105-106, sampling.cpp:78-80
       bx0 = fminf(bx0, x); bx1 = fmaxf(bx1, x); by0 = fminf(by0, y); by1 = fmaxf(by1, y);
       bz0 = fminf(bz0, z); bz1 = fmaxf(bz1, z);
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(1024) void fps_spatial_kernel(const float *__restri
 #pragma unroll
       for (int s = 0; s < PPT; ++s) {
         const float dx = px[s] - x1, dy = py[s] - y1, dz = pz[s] - z1;
-        const float d = dx * dx + dy * dy + dz * dz;
+        const float d = fp_sumsq3(dx, dy, dz);
         const float d2 = vmin(d, tmp[s]);
         tmp[s] = d2;
         tie = tie || (d2 == best);
@@ -434,9 +435,11 @@ __device__ unsigned long long gn_fps_probe[8 * 8];
 #define FPS_PROBE_ADD(i, v) fp_[i] += (unsigned long long)(v)
 #define FPS_PROBE_USE(v) asm volatile("" :: "s"(__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)(v)))))
 #define FPS_PROBE_FLUSH() do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; ++i_) gn_fps_probe[(threadIdx.x >> 6) * 8 + i_] = fp_[i_]; } while (0)
+#if GN_FP == 0
 extern "C" int gn_phase_probe_read_fps(unsigned long long *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(gn_fps_probe), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
 }
+#endif
 #else
 #define FPS_PROBE_INIT()
 #define FPS_PROBE(i)
@@ -587,7 +590,7 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
       float x = 0.f, y = 0.f, z = 0.f, t0 = -1.0f;
       if (pk != 0) {
         x = xyz[k * 3 + 0]; y = xyz[k * 3 + 1]; z = xyz[k * 3 + 2];
-        const float mag = (x * x) + (y * y) + (z * z);
+        const float mag = fp_sumsq3(x, y, z);
         t0 = ((double)mag <= 1e-3) ? -1.0f : 1e10f;     // sampling_gpu.cu:105-106, sampling.cpp:78-80
         x0 = fminf(x0, x); x1_ = fmaxf(x1_, x); y0 = fminf(y0, y); y1_ = fmaxf(y1_, y);
         z0 = fminf(z0, z); z1_ = fmaxf(z1_, z);
@@ -633,7 +636,7 @@ __global__ __launch_bounds__(512) void fps_region_kernel(const float *__restrict
       for (int q = 0; q < SG; ++q) {
         const int s = g * SG + q;
         const float dx = px[s] - x1, dy = py[s] - y1, dz = pz[s] - z1;
-        const float d = dx * dx + dy * dy + dz * dz;
+        const float d = fp_sumsq3(dx, dy, dz);
         const float d2 = vmin(d, tmp[s]);
         tmp[s] = d2;
         tie = tie || (d2 == best);
@@ -777,7 +780,7 @@ __global__ __launch_bounds__(1024) void fps_tier_kernel(const float *__restrict_
     float x = 0.f, y = 0.f, z = 0.f, t0 = -1.0f;
     if (k >= 0) {
       x = xyz[k * 3 + 0]; y = xyz[k * 3 + 1]; z = xyz[k * 3 + 2];
-      const float mag = (x * x) + (y * y) + (z * z);
+      const float mag = fp_sumsq3(x, y, z);
       t0 = ((double)mag <= 1e-3) ? -1.0f : 1e10f;
     }
     tmp[s] = t0;
@@ -827,7 +830,7 @@ __global__ __launch_bounds__(1024) void fps_tier_kernel(const float *__restrict_
       // register indexing and would otherwise prefetch every slot and spill
       if (s >= RS && ((s - RS) & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       const float dx = x - x1, dy = y - y1, dz = z - z1;
-      const float d = dx * dx + dy * dy + dz * dz;
+      const float d = fp_sumsq3(dx, dy, dz);
       const float d2 = vmin(d, tmp[s]);
       tmp[s] = d2;
       const bool gt = d2 > best;
@@ -882,7 +885,7 @@ __global__ __launch_bounds__(1024) void fps_global_kernel(const float *__restric
 
   for (int k = t; k < n; k += NT) {
     const float x = xyz[k * 3 + 0], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
-    const float mag = (x * x) + (y * y) + (z * z);
+    const float mag = fp_sumsq3(x, y, z);
     temp[k] = ((double)mag <= 1e-3) ? -1.0f : 1e10f;
   }
   float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
@@ -896,7 +899,7 @@ __global__ __launch_bounds__(1024) void fps_global_kernel(const float *__restric
     int brank = 0x7fffffff;
     for (int k = t; k < n; k += NT) {
       const float dx = xyz[k * 3 + 0] - x1, dy = xyz[k * 3 + 1] - y1, dz = xyz[k * 3 + 2] - z1;
-      const float d = dx * dx + dy * dy + dz * dz;
+      const float d = fp_sumsq3(dx, dy, dz);
       const float d2 = __builtin_fminf(d, temp[k]);
       temp[k] = d2;
       const int rank = bitrev_bits(k & bmask, lg) * Q + (k >> lg);
@@ -942,8 +945,11 @@ static int fps_cell_forced(int n) {
   return (v == 16 || v == 32) && n >= 1024 && fps_cell_supports(n, v) ? v : 0;
 }
 
+}  // namespace GN_FPNS
 }  // namespace gn
+using namespace gn::GN_FPNS;
 
+#if GN_FP == 0      // a bitwise compare and a size: one copy
 namespace gn {
 // Is `pts2` (n2 points per cloud) exactly the points a previous sampling call picked, in its order -- pts1[inds1[0 .. n2)]?
 // Then the tie step that call reported carries over (tie2 = tie1), else the new cloud is unrelated (tie2 = 0: no promise).
@@ -982,33 +988,37 @@ extern "C" int gn_fps_prefix_check(const float *pts2, const float *pts1, const i
 }
 
 extern "C" size_t gn_fps_workspace_bytes(int b, int n) {
+  using namespace gn;
   if (b <= 0 || n <= 0) return 0;
-  const int bs = gn::fps_ref_block_size(n);
+  const int bs = fps_ref_block_size(n);
   const int Q = (n + bs - 1) / bs;
   const long need = (long)bs * Q;
-  if (need <= 4096 && !gn::fps_cell_forced(n)) return 0;
-  const int forced = gn::fps_cell_forced(n);
-  if (need <= gn::kRegCapacity) {
+  if (need <= 4096 && !fps_cell_forced(n)) return 0;
+  const int forced = fps_cell_forced(n);
+  if (need <= kRegCapacity) {
     // the region / spatial kernels of the model's own 20 000-point level never touch a workspace
     const char *ve = getenv("GN_FPS_VARIANT");
     const int variant = ve ? atoi(ve) : 4;
     const bool region_band = need > 1024 * 16 && need <= 1024 * 20 && (variant == 4 || variant == 3);
     if (region_band && !forced) return 0;
-    return (size_t)b * gn::fps_cell_workspace_bytes_one(n, forced);            // tie-tracking calls
+    return (size_t)b * fps_cell_workspace_bytes_one(n, forced);            // tie-tracking calls
   }
   size_t one = (size_t)n * sizeof(float);                                       // any-n kernel: the reference's `temp`
   if (need <= 1024L * 64) one = 3 * 1024 * 64 * sizeof(float);                  // rank-ordered SoA copy (tier kernel)
-  if (gn::fps_cell_supports(n) || forced) {
-    const size_t cell = gn::fps_cell_workspace_bytes_one(n, forced);            // GN_FPS_CELL=16|32 strides by its own S
+  if (fps_cell_supports(n) || forced) {
+    const size_t cell = fps_cell_workspace_bytes_one(n, forced);            // GN_FPS_CELL=16|32 strides by its own S
     one = one > cell ? one : cell;
   }
   return (size_t)b * one;
 }
 
-extern "C" int gn_furthest_point_sampling(const float *xyz, int b, int n, int m, void *workspace,
+#endif
+
+extern "C" int GN_FP_ENTRY(gn_furthest_point_sampling)(const float *xyz, int b, int n, int m, void *workspace,
                                           int32_t *idx, float *new_xyz, int32_t *tie_out,
                                           const int32_t *prefix_ok, gn_stream_t stream) {
   using namespace gn;
+  GN_FP_DISPATCH(gn_furthest_point_sampling, xyz, b, n, m, workspace, idx, new_xyz, tie_out, prefix_ok, stream);
   GN_REQUIRE(b >= 0 && n >= 1 && m >= 0, "furthest_point_sampling: bad sizes b=%d n=%d m=%d", b, n, m);
   if (b == 0 || m == 0) return GN_OK;
   GN_REQUIRE(xyz && idx, "furthest_point_sampling: null pointer");

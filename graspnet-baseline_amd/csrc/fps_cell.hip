@@ -30,6 +30,7 @@
 #include "fps_util.h"
 
 namespace gn {
+namespace GN_FPNS {
 namespace {
 
 #ifndef FC_ROWS_IN_FLIGHT
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(1024) void fps_cell_kernel(const float *__restrict_
     const int w = (sl + 3 * cy) & (NWC - 1);                              // region (sl, cy) -> chain wave
     const int ol = (sl / NWC) * S + cy;                                   //                -> owner lane in that wave
     const int p = (w * RPW + ol) * ROW + r;
-    const float mag = (x * x) + (y * y) + (z * z);
+    const float mag = fp_sumsq3(x, y, z);
     const f4 v = {x, y, z, ((double)mag <= 1e-3) ? -1.0f : 1e10f};        // sampling_gpu.cu:105-106, sampling.cpp:78-80
     pt[p] = v;
     rk[p] = ((0x7ffffu - (unsigned)rank_of(k)) << 4) | (unsigned)w;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(1024) void fps_cell_kernel(const float *__restrict_
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
           const float dx = v[u][r].x - x1, dy = v[u][r].y - y1, dz = v[u][r].z - z1;
-          const float d = dx * dx + dy * dy + dz * dz;
+          const float d = fp_sumsq3(dx, dy, dz);
           const float d2 = vmin(d, v[u][r].w);
           if (d2 != v[u][r].w) reinterpret_cast<float *>(ptw + (a[u] * RS + r) * 64 + lane)[3] = d2;
           d2s[r] = d2;
@@ -415,7 +416,7 @@ int launch(const float *xyz, int b, int n, int m, int bs, int lg, int Q, unsigne
 
 }  // namespace
 
-#ifdef GN_PHASE_PROBE
+#if defined(GN_PHASE_PROBE) && GN_FP == 0
 extern "C" int gn_phase_probe_read_fps_cell(unsigned long long *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(gn_fpsc_probe), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -1;
 }
@@ -438,4 +439,5 @@ int fps_cell_launch(const float *xyz, int b, int n, int m, int bs, int lg, int Q
   return GN_ERR_INVALID_ARG;
 }
 
+}  // namespace GN_FPNS
 }  // namespace gn

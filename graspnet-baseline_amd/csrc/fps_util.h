@@ -60,7 +60,9 @@ static inline size_t fps_cell_workspace_bytes_one(int n, int force_s = 0) {
   const size_t P = (size_t)c.S * c.S * 64 * c.RS;
   return P * 20 + (((size_t)n + 255) & ~(size_t)255);     // (x,y,z,temp) + key word per slot, slab id per point
 }
+namespace GN_FPNS {      // one copy per evaluation policy (gn_common.h)
 int fps_cell_launch(const float *xyz, int b, int n, int m, int bs, int lg, int Q, unsigned qmagic, void *workspace,
                     int32_t *idx, float *new_xyz, int32_t *tie_out, int force_s, hipStream_t s);
+}
 
 }  // namespace gn

@@ -1,6 +1,9 @@
 // gn_common.cpp -- error state and version string of libgraspnet_hip.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <atomic>
 
 #include "gn_common.h"
 
@@ -12,7 +15,33 @@ void set_error(const char *fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+// evaluation policy of the index-deciding float expressions (gn_common.h): -1 = not set yet -> GN_FP from the environment
+static std::atomic<int> g_fp_policy{-1};
+static int fp_policy_from_name(const char *e) {
+  if (!e || !*e) return 0;
+  if (!strcmp(e, "1") || !strcmp(e, "contracted") || !strcmp(e, "contracted_a") || !strcmp(e, "fma")) return 1;
+  if (!strcmp(e, "2") || !strcmp(e, "contracted_b") || !strcmp(e, "fma_b")) return 2;
+  return 0;       // "0", "as_written", anything else
+}
+int fp_policy() {
+  int p = g_fp_policy.load(std::memory_order_relaxed);
+  if (p < 0) {
+    p = fp_policy_from_name(getenv("GN_FP"));
+    g_fp_policy.store(p, std::memory_order_relaxed);
+  }
+  return p;
+}
 }  // namespace gn
+
+extern "C" int gn_set_fp_policy(int policy) {
+  if (policy < 0 || policy > 2) {
+    gn::set_error("gn_set_fp_policy: policy must be 0 (as written), 1 (contracted) or 2 (contracted, other order), got %d", policy);
+    return GN_ERR_INVALID_ARG;
+  }
+  gn::g_fp_policy.store(policy, std::memory_order_relaxed);
+  return GN_OK;
+}
+extern "C" int gn_get_fp_policy(void) { return gn::fp_policy(); }
 
 extern "C" const char *gn_last_error(void) { return gn::g_err; }
 extern "C" const char *gn_version(void) { return "graspnet_hip 0.5 gfx950"; }

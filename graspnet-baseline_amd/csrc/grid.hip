@@ -12,6 +12,7 @@
 #include "gn_common.h"
 
 namespace gn {
+namespace GN_FPNS {
 
 constexpr int GRID_MAX_DIM = 32;                      // cells per axis (x,y); z uses GRID_MAX_DIMZ
 constexpr int GRID_MAX_DIMZ = 16;
@@ -348,13 +349,13 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void ball_grid_kernel(const float *_
             const float px = pq.x, py = pq.y, pz = pq.z;
             if (CYL) {   // cylinder_query_gpu.cu:36-46
               const float x = px - cx, y = py - cy, z = pz - cz;
-              const float x_rot = r0 * x + r3 * y + r6 * z;
-              const float y_rot = r1 * x + r4 * y + r7 * z;
-              const float z_rot = r2 * x + r5 * y + r8 * z;
-              const float d2 = y_rot * y_rot + z_rot * z_rot;
+              const float x_rot = fp_dot3(r0, x, r3, y, r6, z);
+              const float y_rot = fp_dot3(r1, x, r4, y, r7, z);
+              const float z_rot = fp_dot3(r2, x, r5, y, r8, z);
+              const float d2 = fp_sumsq2(y_rot, z_rot);
               hit = d2 < radius2 && x_rot > hmin && x_rot < hmax;
             } else {     // ball_query_gpu.cu:33-38
-              const float d2 = (cx - px) * (cx - px) + (cy - py) * (cy - py) + (cz - pz) * (cz - pz);
+              const float d2 = fp_sumsq3(cx - px, cy - py, cz - pz);
               hit = d2 < radius2;
             }
             k = __float_as_int(pq.w);
@@ -464,10 +465,10 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void cylinder_unique_grid_kernel(
             // cylinder_query_gpu.cu:36-46
             const gf4 pq = spt[q];
             const float x = pq.x - cx, y = pq.y - cy, z = pq.z - cz;
-            x_rot = r0 * x + r3 * y + r6 * z;
-            const float y_rot = r1 * x + r4 * y + r7 * z;
-            const float z_rot = r2 * x + r5 * y + r8 * z;
-            const float d2 = y_rot * y_rot + z_rot * z_rot;
+            x_rot = fp_dot3(r0, x, r3, y, r6, z);
+            const float y_rot = fp_dot3(r1, x, r4, y, r7, z);
+            const float z_rot = fp_dot3(r2, x, r5, y, r8, z);
+            const float d2 = fp_sumsq2(y_rot, z_rot);
             base = d2 < radius2 && x_rot > hmin && x_rot < hmax[ND - 1];
             k = __float_as_int(pq.w);
           }
@@ -543,14 +544,18 @@ __global__ __launch_bounds__(GQ_WAVES * 64) void cylinder_unique_grid_kernel(
   if (lane == 0) ucount[(size_t)b * m + j] = ucnt;
 }
 
+}  // namespace GN_FPNS
 }  // namespace gn
 
 using namespace gn;
+using namespace gn::GN_FPNS;
 
+#if GN_FP == 0      // binning does not decide an index: one copy
 extern "C" size_t gn_grid_workspace_bytes(int b, int n) {
   if (b <= 0 || n <= 0) return 0;
   return (size_t)b * (sizeof(GridHeader) + (size_t)GRID_CS_STRIDE * 4 + (size_t)n * 16);
 }
+#endif
 
 static void grid_carve(void *ws, int b, int n, GridHeader **hdr, int **cs, float **sxyz, int32_t **sidx) {
   char *p = (char *)ws;
@@ -562,6 +567,7 @@ static void grid_carve(void *ws, int b, int n, GridHeader **hdr, int **cs, float
   *sidx = (int32_t *)p;          // (folded into the points)
 }
 
+#if GN_FP == 0
 extern "C" int gn_grid_build(const float *xyz, int b, int n, float reach, void *workspace, gn_stream_t stream) {
   GN_REQUIRE(b >= 0 && n >= 1 && reach > 0.f, "grid_build: bad sizes");
   if (b == 0) return GN_OK;
@@ -573,9 +579,11 @@ extern "C" int gn_grid_build(const float *xyz, int b, int n, float reach, void *
   GN_CHECK_LAUNCH("grid_build");
   return GN_OK;
 }
+#endif
 
-extern "C" int gn_ball_query_grid(const float *new_xyz, const void *grid, int b, int n, int m, float radius,
+extern "C" int GN_FP_ENTRY(gn_ball_query_grid)(const float *new_xyz, const void *grid, int b, int n, int m, float radius,
                                   int nsample, int32_t *idx, gn_stream_t stream) {
+  GN_FP_DISPATCH(gn_ball_query_grid, new_xyz, grid, b, n, m, radius, nsample, idx, stream);
   GN_REQUIRE(b >= 0 && n >= 1 && m >= 0 && nsample >= 1 && nsample <= 64, "ball_query_grid: bad sizes (nsample <= 64)");
   if (b == 0 || m == 0) return GN_OK;
   GN_REQUIRE(new_xyz && grid && idx, "ball_query_grid: null pointer");
@@ -590,8 +598,9 @@ extern "C" int gn_ball_query_grid(const float *new_xyz, const void *grid, int b,
   return GN_OK;
 }
 
-extern "C" int gn_cylinder_query_grid(const float *new_xyz, const float *rot, const void *grid, int b, int n, int m,
+extern "C" int GN_FP_ENTRY(gn_cylinder_query_grid)(const float *new_xyz, const float *rot, const void *grid, int b, int n, int m,
                                       float radius, float hmin, float hmax, int nsample, int32_t *idx, gn_stream_t stream) {
+  GN_FP_DISPATCH(gn_cylinder_query_grid, new_xyz, rot, grid, b, n, m, radius, hmin, hmax, nsample, idx, stream);
   GN_REQUIRE(b >= 0 && n >= 1 && m >= 0 && nsample >= 1 && nsample <= 64, "cylinder_query_grid: bad sizes (nsample <= 64)");
   if (b == 0 || m == 0) return GN_OK;
   GN_REQUIRE(new_xyz && rot && grid && idx, "cylinder_query_grid: null pointer");
@@ -609,9 +618,10 @@ extern "C" int gn_cylinder_query_grid(const float *new_xyz, const float *rot, co
   return GN_OK;
 }
 
-extern "C" int gn_cylinder_query_unique_grid(const float *new_xyz, const float *rot, const void *grid, int b, int n,
+extern "C" int GN_FP_ENTRY(gn_cylinder_query_unique_grid)(const float *new_xyz, const float *rot, const void *grid, int b, int n,
                                              int m, float radius, float hmin, const float *hmax_host, int ndepth,
                                              int nsample, int32_t *uidx, int32_t *ucount, gn_stream_t stream) {
+  GN_FP_DISPATCH(gn_cylinder_query_unique_grid, new_xyz, rot, grid, b, n, m, radius, hmin, hmax_host, ndepth, nsample, uidx, ucount, stream);
   GN_REQUIRE(b >= 0 && n >= 1 && m >= 0 && nsample >= 1 && nsample <= 64, "cylinder_query_unique_grid: bad sizes");
   if (b == 0 || m == 0) return GN_OK;
   GN_REQUIRE(new_xyz && rot && grid && uidx && ucount && hmax_host, "cylinder_query_unique_grid: null pointer");

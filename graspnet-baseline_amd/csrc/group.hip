@@ -12,6 +12,7 @@
 #include "gn_common.h"
 
 namespace gn {
+namespace GN_FPNS {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(NN_WAVES * 64) void three_nn_kernel(const float *__
   int i1 = 0x7fffffff, i2 = 0x7fffffff, i3 = 0x7fffffff;
   for (int k = lane; k < m; k += 64) {
     const float x = known[k * 3 + 0], y = known[k * 3 + 1], z = known[k * 3 + 2];
-    const float d = (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
+    const float d = fp_sumsq3(ux - x, uy - y, uz - z);       // interpolate_gpu.cu:37
     if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k; }
     else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = k; }
     else if (d < b3) { b3 = d; i3 = k; }
@@ -204,14 +205,17 @@ __global__ __launch_bounds__(256) void three_interpolate_grad_kernel(
 
 static inline int chan_split(int c) { return c < 1 ? 1 : (c > 64 ? 64 : c); }
 
+}  // namespace GN_FPNS
 }  // namespace gn
 
 using namespace gn;
+using namespace gn::GN_FPNS;
 
 #define GN_COMMON_CHECKS(name, ok)                                                     \
   GN_REQUIRE(ok, "%s: bad sizes", name);                                              \
   GN_REQUIRE(b <= 65535, "%s: batch > 65535 unsupported", name)
 
+#if GN_FP == 0      // copies and blends: nothing here depends on the evaluation policy
 extern "C" int gn_gather_points(const float *points, const int32_t *idx, int b, int c, int n, int m,
                                 float *out, gn_stream_t stream) {
   GN_COMMON_CHECKS("gather_points", b >= 0 && c >= 0 && n >= 0 && m >= 0);
@@ -313,8 +317,11 @@ extern "C" int gn_group_points_grad(const float *grad_out, const int32_t *idx, i
   return GN_OK;
 }
 
-extern "C" int gn_three_nn(const float *unknown, const float *known, int b, int n, int m, float *dist2,
+#endif
+
+extern "C" int GN_FP_ENTRY(gn_three_nn)(const float *unknown, const float *known, int b, int n, int m, float *dist2,
                            int32_t *idx, gn_stream_t stream) {
+  GN_FP_DISPATCH(gn_three_nn, unknown, known, b, n, m, dist2, idx, stream);
   GN_COMMON_CHECKS("three_nn", b >= 0 && n >= 0 && m >= 0);
   if (b == 0 || n == 0) return GN_OK;
   GN_REQUIRE(unknown && dist2 && idx && (known || m == 0), "three_nn: null pointer");
@@ -324,6 +331,7 @@ extern "C" int gn_three_nn(const float *unknown, const float *known, int b, int 
   return GN_OK;
 }
 
+#if GN_FP == 0
 extern "C" int gn_three_interpolate(const float *points, const int32_t *idx, const float *weight, int b,
                                     int c, int m, int n, float *out, gn_stream_t stream) {
   GN_COMMON_CHECKS("three_interpolate", b >= 0 && c >= 0 && n >= 0 && m >= 0);
@@ -353,3 +361,4 @@ extern "C" int gn_three_interpolate_grad(const float *grad_out, const int32_t *i
   GN_CHECK_LAUNCH("three_interpolate_grad");
   return GN_OK;
 }
+#endif

@@ -27,6 +27,7 @@
 #include "gn_common.h"
 
 namespace gn {
+namespace GN_FPNS {
 
 __global__ __launch_bounds__(256) void knn_scan_kernel(const float *__restrict__ ref,
                                                   const float *__restrict__ query, int d, int nr, int nq,
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float *__restrict__
       float dd = 0.f;
       for (int h = 0; h < d; ++h) {
         const float t = s_ref[h * tn + rr] - query[(size_t)h * nq + q];
-        dd += t * t;
+        dd = fp_acc_sq(dd, t);                              // knn.cu:89-90
       }
       // stable insertion: after every kept element with dist <= dd
       int pos = cnt;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float *__restrict__
       for (int qi = 0; qi < QW; ++qi) {
         const int q = min(q0 + qi, nq - 1);
         const float t = rv - query[(size_t)h * nq + q];      // wave-uniform address
-        dd[qi] += t * t;
+        dd[qi] = fp_acc_sq(dd[qi], t);                          // knn.cu:89-90
       }
     }
 #pragma unroll
@@ -151,11 +152,14 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float *__restrict__
   }
 }
 
+}  // namespace GN_FPNS
 }  // namespace gn
 
-extern "C" int gn_knn(const float *ref, const float *query, int b, int d, int nr, int nq, int k,
+extern "C" int GN_FP_ENTRY(gn_knn)(const float *ref, const float *query, int b, int d, int nr, int nq, int k,
                       int64_t *idx, float *scratch, gn_stream_t stream) {
   using namespace gn;
+  using namespace gn::GN_FPNS;
+  GN_FP_DISPATCH(gn_knn, ref, query, b, d, nr, nq, k, idx, scratch, stream);
   GN_REQUIRE(b >= 0 && d >= 1 && nr >= 0 && nq >= 0 && k >= 0, "knn: bad sizes");
   if (b == 0 || nq == 0 || k == 0) return GN_OK;
   GN_REQUIRE(ref && query && idx, "knn: null pointer");

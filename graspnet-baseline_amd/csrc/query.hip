@@ -11,6 +11,7 @@
 #include "gn_common.h"
 
 namespace gn {
+namespace GN_FPNS {
 
 constexpr int QUERY_WAVES = 4;  // waves (= centres in flight) per workgroup
 
@@ -62,15 +63,14 @@ __global__ __launch_bounds__(QUERY_WAVES * 64) void query_kernel(
         if (CYL) {
           // cylinder_query_gpu.cu:36-46
           const float x = px[u] - cx[c], y = py[u] - cy[c], z = pz[u] - cz[c];
-          const float x_rot = r[c][0] * x + r[c][3] * y + r[c][6] * z;
-          const float y_rot = r[c][1] * x + r[c][4] * y + r[c][7] * z;
-          const float z_rot = r[c][2] * x + r[c][5] * y + r[c][8] * z;
-          const float d2 = y_rot * y_rot + z_rot * z_rot;
+          const float x_rot = fp_dot3(r[c][0], x, r[c][3], y, r[c][6], z);
+          const float y_rot = fp_dot3(r[c][1], x, r[c][4], y, r[c][7], z);
+          const float z_rot = fp_dot3(r[c][2], x, r[c][5], y, r[c][8], z);
+          const float d2 = fp_sumsq2(y_rot, z_rot);
           hit = d2 < radius2 && x_rot > hmin && x_rot < hmax;
         } else {
           // ball_query_gpu.cu:33-38
-          const float d2 = (cx[c] - px[u]) * (cx[c] - px[u]) + (cy[c] - py[u]) * (cy[c] - py[u]) +
-                           (cz[c] - pz[u]) * (cz[c] - pz[u]);
+          const float d2 = fp_sumsq3(cx[c] - px[u], cy[c] - py[u], cz[c] - pz[u]);
           hit = d2 < radius2;
         }
         hit = hit && k < n;
@@ -135,10 +135,10 @@ __global__ __launch_bounds__(QUERY_WAVES * 64) void cylinder_multi_kernel(
     for (int u = 0; u < U; ++u) {
       const int k = k0 + u * 64 + lane;
       const float x = px[u] - cx, y = py[u] - cy, z = pz[u] - cz;
-      const float x_rot = r0 * x + r3 * y + r6 * z;
-      const float y_rot = r1 * x + r4 * y + r7 * z;
-      const float z_rot = r2 * x + r5 * y + r8 * z;
-      const float d2 = y_rot * y_rot + z_rot * z_rot;
+      const float x_rot = fp_dot3(r0, x, r3, y, r6, z);
+      const float y_rot = fp_dot3(r1, x, r4, y, r7, z);
+      const float z_rot = fp_dot3(r2, x, r5, y, r8, z);
+      const float d2 = fp_sumsq2(y_rot, z_rot);
       const bool base = d2 < radius2 && x_rot > hmin && k < n;
       if (!__ballot(base)) continue;
 #pragma unroll
@@ -209,10 +209,10 @@ __global__ __launch_bounds__(QUERY_WAVES * 64) void cylinder_unique_kernel(
     for (int u = 0; u < U; ++u) {
       const int k = k0 + u * 64 + lane;
       const float x = px[u] - cx, y = py[u] - cy, z = pz[u] - cz;
-      const float x_rot = r0 * x + r3 * y + r6 * z;
-      const float y_rot = r1 * x + r4 * y + r7 * z;
-      const float z_rot = r2 * x + r5 * y + r8 * z;
-      const float d2 = y_rot * y_rot + z_rot * z_rot;
+      const float x_rot = fp_dot3(r0, x, r3, y, r6, z);
+      const float y_rot = fp_dot3(r1, x, r4, y, r7, z);
+      const float z_rot = fp_dot3(r2, x, r5, y, r8, z);
+      const float d2 = fp_sumsq2(y_rot, z_rot);
       const bool base = d2 < radius2 && x_rot > hmin && k < n;
       if (!__ballot(base)) continue;
       unsigned mymask = 0;
@@ -279,25 +279,30 @@ static int launch_query(const float *new_xyz, const float *xyz, const float *rot
   return GN_OK;
 }
 
+}  // namespace GN_FPNS
 }  // namespace gn
+using namespace gn::GN_FPNS;
 
-extern "C" int gn_ball_query(const float *new_xyz, const float *xyz, int b, int n, int m, float radius,
+extern "C" int GN_FP_ENTRY(gn_ball_query)(const float *new_xyz, const float *xyz, int b, int n, int m, float radius,
                              int nsample, int32_t *idx, gn_stream_t stream) {
-  return gn::launch_query<false>(new_xyz, xyz, nullptr, b, n, m, radius, 0.f, 0.f, nsample, idx, stream,
+  GN_FP_DISPATCH(gn_ball_query, new_xyz, xyz, b, n, m, radius, nsample, idx, stream);
+  return launch_query<false>(new_xyz, xyz, nullptr, b, n, m, radius, 0.f, 0.f, nsample, idx, stream,
                                  "ball_query");
 }
 
-extern "C" int gn_cylinder_query(const float *new_xyz, const float *xyz, const float *rot, int b, int n,
+extern "C" int GN_FP_ENTRY(gn_cylinder_query)(const float *new_xyz, const float *xyz, const float *rot, int b, int n,
                                  int m, float radius, float hmin, float hmax, int nsample, int32_t *idx,
                                  gn_stream_t stream) {
-  return gn::launch_query<true>(new_xyz, xyz, rot, b, n, m, radius, hmin, hmax, nsample, idx, stream,
+  GN_FP_DISPATCH(gn_cylinder_query, new_xyz, xyz, rot, b, n, m, radius, hmin, hmax, nsample, idx, stream);
+  return launch_query<true>(new_xyz, xyz, rot, b, n, m, radius, hmin, hmax, nsample, idx, stream,
                                 "cylinder_query");
 }
 
-extern "C" int gn_cylinder_query_multi(const float *new_xyz, const float *xyz, const float *rot, int b, int n, int m,
+extern "C" int GN_FP_ENTRY(gn_cylinder_query_multi)(const float *new_xyz, const float *xyz, const float *rot, int b, int n, int m,
                                        float radius, float hmin, const float *hmax_host, int ndepth, int nsample,
                                        int32_t *idx, gn_stream_t stream) {
   using namespace gn;
+  GN_FP_DISPATCH(gn_cylinder_query_multi, new_xyz, xyz, rot, b, n, m, radius, hmin, hmax_host, ndepth, nsample, idx, stream);
   GN_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0, "cylinder_query_multi: bad sizes");
   if (b == 0 || m == 0 || nsample == 0) return GN_OK;
   GN_REQUIRE(new_xyz && xyz && rot && idx && hmax_host, "cylinder_query_multi: null pointer");
@@ -311,10 +316,11 @@ extern "C" int gn_cylinder_query_multi(const float *new_xyz, const float *xyz, c
   return GN_OK;
 }
 
-extern "C" int gn_cylinder_query_unique(const float *new_xyz, const float *xyz, const float *rot, int b, int n, int m,
+extern "C" int GN_FP_ENTRY(gn_cylinder_query_unique)(const float *new_xyz, const float *xyz, const float *rot, int b, int n, int m,
                                         float radius, float hmin, const float *hmax_host, int ndepth, int nsample,
                                         int32_t *uidx, int32_t *ucount, gn_stream_t stream) {
   using namespace gn;
+  GN_FP_DISPATCH(gn_cylinder_query_unique, new_xyz, xyz, rot, b, n, m, radius, hmin, hmax_host, ndepth, nsample, uidx, ucount, stream);
   GN_REQUIRE(b >= 0 && n >= 1 && m >= 0 && nsample >= 1, "cylinder_query_unique: bad sizes");
   if (b == 0 || m == 0) return GN_OK;
   GN_REQUIRE(new_xyz && xyz && rot && uidx && ucount && hmax_host, "cylinder_query_unique: null pointer");

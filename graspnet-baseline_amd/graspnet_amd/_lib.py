@@ -49,6 +49,8 @@ SIGNATURES = {
     "gn_last_error": (ctypes.c_char_p, []),
     "gn_version": (ctypes.c_char_p, []),
     "gn_abi_version": (_c_int, []),
+    "gn_set_fp_policy": (_c_int, [_c_int]),
+    "gn_get_fp_policy": (_c_int, []),
     "gn_stream_capture_id": (_c_int, [_c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
     "gn_fps_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
     "gn_fps_prefix_check": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p,
@@ -188,6 +190,18 @@ def check(status, what):
     if status != 0:
         msg = lib().gn_last_error().decode("utf-8", "replace")
         raise RuntimeError("%s failed (gn_status %d): %s" % (what, status, msg))
+
+
+FP_POLICIES = {"as_written": 0, "contracted": 1, "contracted_b": 2}
+
+
+def set_fp_policy(policy):
+    """How the index-deciding float expressions are evaluated (include/graspnet_hip.h gn_set_fp_policy): "as_written" (default:
+    no FMA contraction), "contracted" (LLVM / NVVM order) or "contracted_b"; or 0 / 1 / 2.  Returns the previous policy's name."""
+    names = {v: k for k, v in FP_POLICIES.items()}
+    prev = names[lib().gn_get_fp_policy()]
+    check(lib().gn_set_fp_policy(FP_POLICIES[policy] if isinstance(policy, str) else int(policy)), "set_fp_policy")
+    return prev
 
 
 def capture_id(stream):

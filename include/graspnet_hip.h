@@ -58,9 +58,26 @@ int gn_abi_version(void);
  * inside a capture only inside that same capture. */
 int gn_stream_capture_id(gn_stream_t stream, unsigned long long *id);
 
+/* Evaluation policy of the float expressions that DECIDE AN INDEX -- the squared distances of sampling_gpu.cu:108-109,
+ * ball_query_gpu.cu:36-37, interpolate_gpu.cu:37, knn.cu:89-90 and the rotated coordinates of cylinder_query_gpu.cu:39-45:
+ *   0 (default)  as written: one rounding per operation, left to right, no FMA contraction -- what a CPU build of the same
+ *                expressions computes (the reference's own knn_cpu.cpp);
+ *   1            contracted the way LLVM / NVVM fuse the expression tree:  a*a + b*b + c*c = fma(c, c, fma(a, a, b*b));
+ *   2            contracted in the other plausible order:                  a*a + b*b + c*c = fma(c, c, fma(b, b, a*a)).
+ * The reference builds its CUDA kernels with plain `nvcc -O2` (pointnet2/setup.py:24-27), i.e. --fmad=true, so ITS binary
+ * contracts these expressions; which order it takes cannot be observed without nvcc.  A maintainer with a CUDA box picks
+ * the policy whose indices match theirs (profiles/parity_r05.json holds how many indices each choice moves).  Process-wide;
+ * the GN_FP environment variable (as_written | contracted | contracted_b) sets the initial value.  Affects
+ * gn_furthest_point_sampling, gn_ball_query*, gn_cylinder_query*, gn_three_nn, gn_knn and gn_graspnet_forward. */
+int gn_set_fp_policy(int policy);
+int gn_get_fp_policy(void);
+
 /* ------------------------------------------------------------------ *
  *  pointnet2._ext operators                                          *
  * ------------------------------------------------------------------ */
+
+/* The operators whose results depend on the evaluation policy also exist under policy-suffixed names (`_fp1`, `_fp2`: the
+ * copies compiled with -DGN_FP=1 / 2); the plain names dispatch to them, nothing else should call them. */
 
 /* furthest_point_sampling(points (B,N,3) f32, nsamples) -> idx (B,M) i32
  * replaces sampling.cpp:70-91 + sampling_gpu.cu:74-234.

@@ -23,9 +23,9 @@ _lib = None
 
 def build(force=False):
     """Compile libgn_oracle.so with gcc (seconds)."""
-    src = os.path.join(_HERE, "gn_oracle.c")
+    srcs = [os.path.join(_HERE, "gn_oracle.c"), os.path.join(_HERE, "gn_oracle_fp.inc")]
     if (not force and os.path.exists(_LIB_PATH)
-            and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)):
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src) for src in srcs)):
         return _LIB_PATH
     subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
     return _LIB_PATH
@@ -39,6 +39,21 @@ def lib():
         _lib.gno_opt_n_threads.restype = ctypes.c_int
         _lib.gno_num_threads.restype = ctypes.c_int
     return _lib
+
+
+FP_POLICIES = {"as_written": 0, "contracted": 1, "contracted_b": 2}
+
+
+def set_fp_policy(policy):
+    """How the index-deciding float expressions are evaluated (gn_oracle_fp.inc): "as_written" (default), "contracted"
+    (fma(c,c,fma(a,a,b*b)): LLVM / NVVM order) or "contracted_b" (fma(c,c,fma(b,b,a*a))) -- the same switch as the HIP
+    library's gn_set_fp_policy.  Returns the previous policy's name."""
+    names = {v: k for k, v in FP_POLICIES.items()}
+    l = lib()
+    l.gno_get_fp_policy.restype = ctypes.c_int
+    prev = names[int(l.gno_get_fp_policy())]
+    l.gno_set_fp_policy(ctypes.c_int(FP_POLICIES[policy] if isinstance(policy, str) else int(policy)))
+    return prev
 
 
 def num_threads():

@@ -351,6 +351,27 @@ def test_baseline_configs_at_their_own_size(net, model_oracle, state_dict, name,
     PU.assert_parity(name, ep, pr, rep, rp, tru, tp, MATH)
 
 
+@pytest.mark.parametrize("policy", ["contracted", "contracted_b"])
+def test_model_parity_under_the_contracted_evaluation_policies(net, model_oracle, oracle, state_dict, policy):
+    """the whole forward with the index-deciding expressions contracted into FMAs on BOTH sides (gn_set_fp_policy /
+    oracle.set_fp_policy: what the reference's nvcc build does, pointnet2/setup.py:24-27): same bar as every other
+    model-level case -- indices bit-exact, THE RULE, float64 yardstick"""
+    from graspnet_amd import pred_decode, set_fp_policy, synthetic as S
+    cl = S.make_batch(1000, 2, 20000, "uniform")
+    prev_h, prev_o = set_fp_policy(policy), oracle.set_fp_policy(policy)
+    try:
+        rep = model_oracle.forward({"point_clouds": cl.clone()}, state_dict)
+        rp = model_oracle.pred_decode(rep)
+        tru = model_oracle.forward({"point_clouds": cl.clone()}, state_dict, f64=True, force_top_view_inds=rep["grasp_top_view_inds"])
+        ep = net({"point_clouds": cl.cuda()})
+        pr = pred_decode(ep)
+        torch.cuda.synchronize()
+        PU.assert_parity("evaluation policy %r: B=2 N=20000" % policy, ep, pr, rep, rp, tru, model_oracle.pred_decode(tru), MATH)
+    finally:
+        set_fp_policy(prev_h)
+        oracle.set_fp_policy(prev_o)
+
+
 def _variants_module(golden_dir):
     import importlib.util
     spec = importlib.util.spec_from_file_location("make_golden_variants", os.path.join(golden_dir, "make_golden_variants.py"))

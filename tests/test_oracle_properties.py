@@ -168,3 +168,57 @@ def test_knn_topk_property(oracle):
     d = ((r[0].T[None] - q[0].T[:, None]) ** 2).sum(-1)
     want = torch.argsort(d, dim=1, stable=True)[:, :4].T + 1
     assert torch.equal(idx[0], want)
+
+
+def _round_f32(fr):
+    """round-to-nearest-even of an exact Fraction to float32 (no double rounding)"""
+    from fractions import Fraction
+    import math
+    if fr == 0:
+        return np.float32(0.0)
+    sign = -1 if fr < 0 else 1
+    a = abs(fr)
+    e = math.floor(math.log2(float(a)))
+    while Fraction(2) ** e > a:
+        e -= 1
+    while Fraction(2) ** (e + 1) <= a:
+        e += 1
+    e = max(e, -126)                               # subnormals share the exponent -126
+    q = a / (Fraction(2) ** (e - 23))              # in units of the last place
+    n = q.numerator // q.denominator
+    rem = q - n
+    if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and (n & 1)):
+        n += 1
+    return np.float32(sign * float(Fraction(n) * Fraction(2) ** (e - 23)))
+
+
+def test_evaluation_policies_are_what_they_say(oracle):
+    """the oracle's three evaluation policies of a*a + b*b + c*c (gn_oracle_fp.inc) against EXACT rational arithmetic with one
+    explicit round-to-nearest-even per operation: policy 0 rounds every product and sum, policy 1 = fma(c,c,fma(a,a,b*b)),
+    policy 2 = fma(c,c,fma(b,b,a*a)) -- through three_nn's squared distances (the one operator that RETURNS the value) and
+    knn's accumulation s = fma(t,t,s); and the policies do differ on some of these inputs (else the switch tests nothing)"""
+    from fractions import Fraction as F
+    rng = np.random.default_rng(11)
+    u = torch.from_numpy(rng.uniform(-0.3, 0.3, (1, 40, 3)).astype(np.float32))
+    k = torch.from_numpy(rng.uniform(-0.3, 0.3, (1, 1, 3)).astype(np.float32))      # one known point: dist2[:, :, 0] is its distance
+
+    def exact(a, b, c, pol):
+        a, b, c = F(float(a)), F(float(b)), F(float(c))
+        r = _round_f32
+        if pol == 0:
+            return r(F(float(r(F(float(r(a * a))) + F(float(r(b * b)))))) + F(float(r(c * c))))
+        if pol == 1:
+            return r(c * c + F(float(r(a * a + F(float(r(b * b)))))))
+        return r(c * c + F(float(r(b * b + F(float(r(a * a)))))))
+    got = {}
+    try:
+        for name, pol in (("as_written", 0), ("contracted", 1), ("contracted_b", 2)):
+            oracle.set_fp_policy(name)
+            d2, _ = oracle.three_nn(u, k)
+            got[pol] = d2[0, :, 0].numpy().copy()
+            for j in range(40):
+                dx, dy, dz = (np.float32(u[0, j, i]) - np.float32(k[0, 0, i]) for i in range(3))
+                assert got[pol][j] == exact(dx, dy, dz, pol), (name, j)
+    finally:
+        oracle.set_fp_policy("as_written")
+    assert (got[0] != got[1]).any() and (got[1] != got[2]).any()

@@ -124,6 +124,72 @@ __global__ __launch_bounds__(256) void fe_sample_kernel(const uint16_t *__restri
   if (out_pix) out_pix[(size_t)b * n + i] = p;
 }
 
+// cloud_masked itself (dataset/graspnet_dataset.py:133, demo.py:455: `cloud[mask]`): valid pixel i -> row i, rows past the
+// image's count (or past nmax) zero -- the scene every caller hands to the collision detector (test.py:92-96 with
+// return_raw_cloud=True; demo.py builds it from cloud_masked), as opposed to the num_point rows sampled for the network
+__global__ __launch_bounds__(256) void fe_masked_cloud_kernel(const uint16_t *__restrict__ depth, int w, int npix, double fx, double fy,
+                                                              double cx, double cy, double factor,
+                                                              const int32_t *__restrict__ valid_pix, const int32_t *__restrict__ count,
+                                                              int nmax, float *__restrict__ out, int32_t *__restrict__ out_count) {
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  const int cnt = min(count[b], nmax);
+  if (i == 0 && out_count) out_count[b] = cnt;
+  if (i >= nmax) return;
+  float *o = out + ((size_t)b * nmax + i) * 3;
+  if (i >= cnt) { o[0] = o[1] = o[2] = 0.f; return; }
+  const int p = valid_pix[(size_t)b * npix + i];
+  const int row = p / w, col = p - row * w;
+  const double z = (double)depth[(size_t)b * npix + p] / factor;      // data_utils.py:37
+  o[0] = (float)(((double)col - cx) * z / fx);                        // :38
+  o[1] = (float)(((double)row - cy) * z / fy);                        // :39
+  o[2] = (float)z;
+}
+
+// ---- the draw (dataset/graspnet_dataset.py:139-145, demo.py:458-463) -------------------------------------------------
+//   len(cloud_masked) >= num_point:  idxs = np.random.choice(len, num_point, replace=False)
+//   else:                            idxs = concat(arange(len), np.random.choice(len, num_point - len, replace=True))
+// numpy's stream cannot be reproduced on a device; what CAN be kept is the distribution: WITHOUT replacement when there are
+// enough valid pixels (no duplicated points reach the sampler and the groupers, as in the reference).  position i = P(i) for
+// a keyed pseudo-random PERMUTATION P of [0, count): a 4-round Feistel network over the next even power of two >= count,
+// cycle-walked back into range (a bijection on [0, 2^k) restricted to [0, count) by iterating until the value falls below
+// count is a bijection on [0, count): num_point distinct positions, one independent hash chain per output, no sort, no
+// atomics, integer arithmetic only -- oracle/post_oracle.py draw_positions restates it bit for bit).
+__device__ __host__ __forceinline__ uint32_t fe_hash32(uint32_t x) {      // lowbias32
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__global__ __launch_bounds__(256) void fe_draw_kernel(const int32_t *__restrict__ count, const uint32_t *__restrict__ keys, int n,
+                                                      int32_t *__restrict__ positions) {
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (i >= n) return;
+  const int cnt = count[b];
+  const uint32_t k0 = keys[b * 4 + 0], k1 = keys[b * 4 + 1], k2 = keys[b * 4 + 2], k3 = keys[b * 4 + 3];
+  int pos = 0;
+  if (cnt <= 0) {
+    pos = 0;
+  } else if (cnt < n) {
+    // fewer valid pixels than points: all of them first, then draws with replacement
+    pos = i < cnt ? i : (int)(((unsigned long long)fe_hash32((uint32_t)i * 0x9e3779b9u ^ k0) * (unsigned long long)cnt) >> 32);
+  } else {
+    int half = 1;                                      // bits per Feistel half: 2 * half >= ceil(log2(cnt))
+    while ((1ll << (2 * half)) < (long long)cnt) ++half;
+    const uint32_t hm = (1u << half) - 1u;
+    uint32_t x = (uint32_t)i;
+    for (long long it = 0; it < (1ll << (2 * half)); ++it) {      // cycle walk: expected < 4 turns, always ends
+      uint32_t l = x >> half, r = x & hm;
+      uint32_t t;
+      t = l ^ (fe_hash32(r ^ k0) & hm); l = r; r = t;
+      t = l ^ (fe_hash32(r ^ k1) & hm); l = r; r = t;
+      t = l ^ (fe_hash32(r ^ k2) & hm); l = r; r = t;
+      t = l ^ (fe_hash32(r ^ k3) & hm); l = r; r = t;
+      x = (l << half) | r;
+      if (x < (uint32_t)cnt) break;
+    }
+    pos = (int)x;
+  }
+  positions[(size_t)b * n + i] = pos;
+}
+
 static inline int fe_nseg(long npix) { return (int)((npix + FE_SEG - 1) / FE_SEG); }
 
 }  // namespace gn
@@ -166,5 +232,27 @@ extern "C" int gn_depth_sample_cloud(const uint16_t *depth, int b, int h, int w,
   hipLaunchKernelGGL(fe_sample_kernel, dim3((n + 255) / 256, b), dim3(256), 0, as_stream(stream), depth, w, h * w, fx, fy, cx, cy,
                      factor_depth, valid_pix, count, positions, random_words, n, out, out_pix);
   GN_CHECK_LAUNCH("depth_sample_cloud");
+  return GN_OK;
+}
+
+extern "C" int gn_depth_masked_cloud(const uint16_t *depth, int b, int h, int w, double fx, double fy, double cx, double cy,
+                                     double factor_depth, const int32_t *valid_pix, const int32_t *count, int nmax, float *out,
+                                     int32_t *out_count, gn_stream_t stream) {
+  GN_REQUIRE(b >= 0 && h > 0 && w > 0 && nmax >= 0 && factor_depth != 0.0 && fx != 0.0 && fy != 0.0, "depth_masked_cloud: bad sizes");
+  GN_REQUIRE((long)h * w < 0x7fffffffL && b <= 65535 && nmax <= h * w, "depth_masked_cloud: image / batch too large or nmax > H*W");
+  if (b == 0) return GN_OK;
+  GN_REQUIRE(depth && valid_pix && count && (out || nmax == 0), "depth_masked_cloud: null pointer");
+  hipLaunchKernelGGL(fe_masked_cloud_kernel, dim3((nmax > 0 ? nmax + 255 : 256) / 256, b), dim3(256), 0, as_stream(stream), depth, w, h * w,
+                     fx, fy, cx, cy, factor_depth, valid_pix, count, nmax, out, out_count);
+  GN_CHECK_LAUNCH("depth_masked_cloud");
+  return GN_OK;
+}
+
+extern "C" int gn_depth_draw_positions(const int32_t *count, const uint32_t *keys, int b, int n, int32_t *positions, gn_stream_t stream) {
+  GN_REQUIRE(b >= 0 && n >= 0 && b <= 65535, "depth_draw_positions: bad sizes");
+  if (b == 0 || n == 0) return GN_OK;
+  GN_REQUIRE(count && keys && positions, "depth_draw_positions: null pointer");
+  hipLaunchKernelGGL(fe_draw_kernel, dim3((n + 255) / 256, b), dim3(256), 0, as_stream(stream), count, keys, n, positions);
+  GN_CHECK_LAUNCH("depth_draw_positions");
   return GN_OK;
 }

@@ -132,6 +132,9 @@ SIGNATURES = {
     "gn_depth_sample_cloud": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                        ctypes.c_double, ctypes.c_double, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int,
                                        _c_void_p, _c_void_p, _c_void_p]),
+    "gn_depth_masked_cloud": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                       ctypes.c_double, ctypes.c_double, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "gn_depth_draw_positions": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
     "gn_voxel_batched_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
     "gn_voxel_down_sample_batched": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, ctypes.c_double, _c_void_p, _c_void_p,
                                              _c_void_p, _c_void_p, _c_void_p]),

@@ -476,24 +476,57 @@ class GraphedGraspNet:
     the returned end_points / grasps / counts are the graph's static output tensors (overwritten by the
     next call).  Nothing in the C ABI allocates or synchronises, which is what makes the capture legal."""
 
-    def __init__(self, net, batch, points, warmup=2, fork_streams=True, post=None):
+    def __init__(self, net, batch, points, warmup=2, fork_streams=True, post=None, scene_points=None, front=None):
         """post: None, or a dict of postprocess.grasp_pipeline() keyword arguments -- the graph then also holds the steps every
         caller of the reference runs on the host after pred_decode (voxel down-sample of each scene, collision filter, sort +
         NMS: test.py:88-96, demo_pointcloud.py:228-249) and a call returns
-        (end_points, grasps, counts, final_rows (B,M,17), kept (B,), collision_mask (B,M))."""
+        (end_points, grasps, counts, final_rows (B,M,17), kept (B,), collision_mask (B,M), voxel_status (B,)).
+        scene_points: with post, the graph checks the grasps against a SEPARATE scene cloud of up to that many points per
+        scene -- the reference's callers use the raw masked cloud there (test.py:92 return_raw_cloud=True, demo.py:481), several
+        times larger than the `points` sampled for the network; pass it to __call__(clouds, scene=, scene_n_valid=).  Without
+        scene_points the sampled input cloud itself is the scene (fewer occupied voxels, lower IoUs: NOT the reference's check).
+        front: None, or dict(height=, width=, intrinsics=(fx, fy, cx, cy, factor_depth)[, depth_min=, depth_max=,
+        scene_points=]) -- the graph then starts from the IMAGES: __call__(depth (B,H,W) u16, mask, seed=) runs
+        postprocess.image_to_grasps (valid-pixel compaction, the draw without replacement, cloud, forward, decode and, with post,
+        the collision filter against the raw masked cloud) as ONE replay and returns its dict."""
         from . import postprocess
         self.net = net
         self.post = None if post is None else dict(post)
+        self.front = None if front is None else dict(front)
         dev = net.device
-        self.static_in = torch.zeros((batch, points, 3), dtype=torch.float32, device=dev)
-        # a cloud of all-equal points is a legal input but not a typical one: warm up on spread-out coordinates
-        self.static_in.uniform_(-0.3, 0.3)
-        self.static_in[..., 2] += 0.5
+        self.static_scene = self.static_scene_n = None
+        if self.front is not None:
+            h, w = int(self.front["height"]), int(self.front["width"])
+            self.static_depth = torch.full((batch, h, w), 600, dtype=torch.int16, device=dev)      # 16-bit words (uint16 view)
+            self.static_mask = torch.ones((batch, h, w), dtype=torch.uint8, device=dev)
+            self.static_keys = postprocess.draw_keys(0, batch, dev)
+            self.static_in = None
+        else:
+            self.static_in = torch.zeros((batch, points, 3), dtype=torch.float32, device=dev)
+            # a cloud of all-equal points is a legal input but not a typical one: warm up on spread-out coordinates
+            self.static_in.uniform_(-0.3, 0.3)
+            self.static_in[..., 2] += 0.5
+            if self.post is not None and scene_points is not None:
+                self.static_scene = torch.zeros((batch, int(scene_points), 3), dtype=torch.float32, device=dev)
+                n0 = min(points, int(scene_points))
+                self.static_scene[:, :n0] = self.static_in[:, :n0]
+                self.static_scene_n = torch.full((batch,), n0, dtype=torch.int32, device=dev)
 
         def run():
+            if self.front is not None:
+                f = self.front
+                return postprocess.image_to_grasps(net, self.static_depth, self.static_mask, f["intrinsics"], num_point=points,
+                                                   keys=self.static_keys, post=self.post, scene_points=f.get("scene_points"),
+                                                   depth_min=f.get("depth_min", 0.0), depth_max=f.get("depth_max", float("inf")))
             ep = net({"point_clouds": self.static_in})
             g, c = net.decode_padded(ep)
-            tail = postprocess.grasp_pipeline(self.static_in, g, c, **self.post) if self.post is not None else ()
+            tail = ()
+            if self.post is not None:
+                if self.static_scene is not None:
+                    tail = postprocess.grasp_pipeline(self.static_scene, g, c, n_valid=self.static_scene_n, return_status=True,
+                                                      **self.post)
+                else:
+                    tail = postprocess.grasp_pipeline(self.static_in, g, c, return_status=True, **self.post)
             return (ep, g, c) + tuple(tail)
 
         side = torch.cuda.Stream(device=dev)
@@ -510,10 +543,38 @@ class GraphedGraspNet:
                 self.outputs = run()
         finally:
             net.fork = fork
-        self.end_points, self.grasps, self.counts = self.outputs[:3]
+        if self.front is None:
+            self.end_points, self.grasps, self.counts = self.outputs[:3]
+        else:
+            self.end_points, self.grasps, self.counts = (self.outputs[k] for k in ("end_points", "grasps", "counts"))
 
-    def __call__(self, point_clouds):
+    def __call__(self, point_clouds, mask=None, seed=None, keys=None, scene=None, scene_n_valid=None):
+        """clouds (B,N,3) [, scene=(B,n<=scene_points,3), scene_n_valid=(B,)]; or, built with front=: depth (B,H,W) 16-bit,
+        mask (B,H,W) uint8 / bool or None (= every pixel), seed or keys (B,4) for the draw (default: the previous keys)."""
+        if self.front is not None:
+            from . import postprocess
+            d = point_clouds
+            self.static_depth.copy_(d.view(torch.int16) if d.dtype == torch.uint16 else d, non_blocking=True)
+            if mask is None:
+                self.static_mask.fill_(1)
+            else:
+                self.static_mask.copy_(mask.view(torch.uint8) if mask.dtype == torch.bool else mask, non_blocking=True)
+            if keys is None and seed is not None:
+                keys = postprocess.draw_keys(seed, self.static_keys.shape[0])
+            if keys is not None:
+                self.static_keys.copy_(keys.view(torch.int32) if keys.dtype == torch.uint32 else keys, non_blocking=True)
+            self.graph.replay()
+            return self.outputs
         self.static_in.copy_(point_clouds[..., 0:3], non_blocking=True)
+        if self.static_scene is not None:
+            if scene is None:       # no separate scene given: the sampled cloud (as without scene_points)
+                scene, scene_n_valid = point_clouds[..., 0:3], None
+            n = min(int(scene.shape[1]), int(self.static_scene.shape[1]))
+            self.static_scene[:, :n].copy_(scene[:, :n, 0:3], non_blocking=True)
+            if scene_n_valid is None:
+                self.static_scene_n.fill_(n)
+            else:
+                self.static_scene_n.copy_(torch.clamp(scene_n_valid.to(torch.int32), max=n), non_blocking=True)
         self.graph.replay()
         return self.outputs
 
@@ -540,11 +601,12 @@ class PipelinedGraspNet:
         def __init__(self, end_points, grasps, counts, event, stream):
             self.end_points, self.grasps, self.counts, self.event, self.stream = end_points, grasps, counts, event, stream
 
-        final_rows = kept = collision_mask = None      # set when the pipeline was built with post=...
+        final_rows = kept = collision_mask = voxel_status = None      # set when the pipeline was built with post=...
 
         def _tensors(self):
             priv = self.end_points.get("_gn") or {}
-            vals = list(self.end_points.values()) + list(priv.values()) + [self.final_rows, self.kept, self.collision_mask]
+            vals = list(self.end_points.values()) + list(priv.values()) + [self.final_rows, self.kept, self.collision_mask,
+                                                                                self.voxel_status]
             return [self.grasps, self.counts] + [v for v in vals if torch.is_tensor(v) and v.is_cuda]
 
         def _register(self, cur):
@@ -570,8 +632,10 @@ class PipelinedGraspNet:
 
     def __init__(self, net, depth=12, post=None, throughput_tiles=True):
         """post: None, or a dict of postprocess.grasp_pipeline() keyword arguments: every submitted batch then also goes through
-        the collision filter + sort + NMS on its stream (no host read), and the ticket carries `final_rows` (B,M,17), `kept` (B,)
-        and `collision_mask` (B,M) beside the raw grasps.
+        the collision filter + sort + NMS on its stream (no host read), and the ticket carries `final_rows` (B,M,17), `kept` (B,),
+        `collision_mask` (B,M) and `voxel_status` (B,) beside the raw grasps.  submit(clouds, scene=, scene_n_valid=) checks the
+        grasps against a separate scene cloud -- the reference's callers use the raw masked cloud (test.py:92, demo.py:481), not
+        the points sampled for the network; without it the sampled cloud is the scene.
         throughput_tiles: run the per-point chains in their throughput tile shapes (GraspNet.throughput) while submitting."""
         self.net = net
         self.throughput_tiles = bool(throughput_tiles) and int(depth) > 1
@@ -579,7 +643,7 @@ class PipelinedGraspNet:
         self.streams = [torch.cuda.Stream(device=net.device) for _ in range(max(1, int(depth)))]
         self._i = 0
 
-    def submit(self, point_clouds):
+    def submit(self, point_clouds, scene=None, scene_n_valid=None):
         st = self.streams[self._i % len(self.streams)]
         self._i += 1
         st.wait_stream(torch.cuda.current_stream(point_clouds.device))     # the input may still be in flight there
@@ -593,13 +657,17 @@ class PipelinedGraspNet:
             tail = None
             if self.post is not None:
                 from . import postprocess
-                tail = postprocess.grasp_pipeline(point_clouds[..., 0:3], grasps, counts, **self.post)
+                tail = postprocess.grasp_pipeline(point_clouds[..., 0:3] if scene is None else scene, grasps, counts,
+                                                  n_valid=None if scene is None else scene_n_valid, return_status=True, **self.post)
             ev = torch.cuda.Event()
             ev.record(st)
         point_clouds.record_stream(st)
+        for t_in in (scene, scene_n_valid):
+            if t_in is not None:
+                t_in.record_stream(st)
         t = PipelinedGraspNet.Ticket(ep, grasps, counts, ev, st)
         if tail is not None:
-            t.final_rows, t.kept, t.collision_mask = tail
+            t.final_rows, t.kept, t.collision_mask, t.voxel_status = tail
         return t
 
 

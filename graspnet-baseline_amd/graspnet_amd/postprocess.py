@@ -68,15 +68,81 @@ def valid_pixels(depth, mask, factor_depth, depth_min=0.0, depth_max=float("inf"
     return vpix, cnt
 
 
+def _hash32(x):
+    x &= 0xffffffff
+    x ^= x >> 16
+    x = (x * 0x7feb352d) & 0xffffffff
+    x ^= x >> 15
+    x = (x * 0x846ca68b) & 0xffffffff
+    x ^= x >> 16
+    return x
+
+
+def draw_keys(seed, nimages, device=None):
+    """(nimages, 4) round keys of the device-side draw from one seed (host arithmetic, 16 bytes per image):
+    key[b][r] = hash32(seed + 0x9e3779b9 * (4 b + r + 1)); int32 tensor holding the 32-bit words."""
+    seed = int(seed) & 0xffffffff
+    words = [[_hash32(seed + 0x9e3779b9 * (4 * b + r + 1)) for r in range(4)] for b in range(int(nimages))]
+    t = torch.tensor([[w - (1 << 32) if w >= (1 << 31) else w for w in row] for row in words], dtype=torch.int32).reshape(-1, 4)
+    return t if device is None else t.to(device)
+
+
+def draw_positions(count, num_point, keys):
+    """The reference's draw (dataset/graspnet_dataset.py:139-145, demo.py:458-463) on the device: count (B,) i32 valid pixels
+    per image, keys (B,4) 32-bit words (draw_keys) -> positions (B,num_point) i32 into the valid list -- num_point DISTINCT
+    positions when count >= num_point (np.random.choice(..., replace=False)), else all of them followed by draws with
+    replacement.  No host read; hipGraph-capturable."""
+    if not count.is_cuda:
+        raise RuntimeError("CPU not supported")
+    B = count.numel()
+    keys = keys.to(device=count.device).contiguous()
+    if keys.dtype not in (torch.int32, torch.uint32) or keys.numel() != 4 * B:
+        raise RuntimeError("keys must be (B, 4) 32-bit words")
+    pos = torch.empty((B, int(num_point)), dtype=torch.int32, device=count.device)
+    with torch.cuda.device(count.device):
+        L.check(L.lib().gn_depth_draw_positions(count.data_ptr(), keys.data_ptr(), B, int(num_point), pos.data_ptr(), _stream(count)),
+                "depth_draw_positions")
+    return pos
+
+
+def masked_cloud(depth, mask, fx, fy, cx, cy, factor_depth, max_points=None, depth_min=0.0, depth_max=float("inf"),
+                 valid=None):
+    """cloud_masked of the reference (`cloud[mask]`: dataset/graspnet_dataset.py:133, demo.py:455) for a batch of images, on the
+    device: -> (cloud (B,max_points,3) f32 with zero rows behind each image's points, n_valid (B,) i32).  This is the scene the
+    reference's callers give to the collision detector (test.py:92-96 return_raw_cloud=True; demo.py:481), several times
+    larger than the num_point points the network sees.  max_points: rows kept per image (default H*W; an image with more
+    valid pixels is cut there).  valid: (valid_pix, count) from valid_pixels() to share the compaction with the sampler."""
+    if not depth.is_cuda:
+        raise RuntimeError("CPU not supported")
+    if depth.dim() == 2:
+        depth = depth.unsqueeze(0)
+        mask = None if mask is None else mask.unsqueeze(0)
+    depth = _as_u16(depth)
+    B, h, w = depth.shape
+    vpix, cnt = valid if valid is not None else valid_pixels(depth, mask, factor_depth, depth_min, depth_max)
+    nmax = h * w if max_points is None else min(int(max_points), h * w)
+    out = torch.empty((B, nmax, 3), dtype=torch.float32, device=depth.device)
+    nv = torch.empty((B,), dtype=torch.int32, device=depth.device)
+    with torch.cuda.device(depth.device):
+        L.check(L.lib().gn_depth_masked_cloud(depth.data_ptr(), B, h, w, float(fx), float(fy), float(cx), float(cy),
+                                              float(factor_depth), vpix.data_ptr(), cnt.data_ptr(), nmax, out.data_ptr(),
+                                              nv.data_ptr(), _stream(depth)), "depth_masked_cloud")
+    return out, nv
+
+
 def depth_to_cloud_masked(depth, mask, fx, fy, cx, cy, factor_depth, num_point, positions=None, random_words=None, seed=None,
-                          depth_min=0.0, depth_max=float("inf"), return_pix=False):
+                          depth_min=0.0, depth_max=float("inf"), return_pix=False, keys=None, valid=None):
     """The reference's host-side front end (dataset/graspnet_dataset.py:104-147, demo.py:449-463) for a batch of images on the
     device: cloud from depth, keep workspace-mask & depth > 0 pixels, take num_point of them.
       depth (B,H,W) or (H,W) 16-bit CUDA tensor, mask the same shape (uint8 / bool) or None
       positions (B,num_point) int: the caller's own draw into the valid list -- with the reference's `idxs` the cloud is the
-          reference's bit for bit; or random_words (B,num_point) 32-bit: all valid pixels first when there are fewer than
-          num_point (as the reference does), then floor(word * count / 2^32), i.e. with replacement; or seed: the words come
-          from torch's device generator seeded with it.  Nothing is read back.
+          reference's bit for bit; or seed / keys (B,4): the device's own draw (draw_positions) -- WITHOUT replacement when
+          the image has at least num_point valid pixels, like the reference's np.random.choice(..., replace=False), all valid
+          pixels followed by draws with replacement when it has fewer; or random_words (B,num_point) 32-bit: all valid
+          pixels first when there are fewer than num_point, then floor(word * count / 2^32) -- WITH replacement whatever the
+          count (1-4 % duplicated points at 20 000 of a few hundred thousand: NOT what the reference feeds its sampler; kept
+          for callers that bring their own random words).  Default (nothing given): seed 0.  Nothing is read back.
+      valid: (valid_pix, count) from valid_pixels(), to share the compaction with masked_cloud().
     -> cloud (B,num_point,3) f32, count (B,) i32 [, pix (B,num_point) i32]"""
     if not depth.is_cuda:
         raise RuntimeError("CPU not supported")
@@ -90,17 +156,16 @@ def depth_to_cloud_masked(depth, mask, fx, fy, cx, cy, factor_depth, num_point, 
     B, h, w = depth.shape
     dev = depth.device
     n = int(num_point)
-    vpix, cnt = valid_pixels(depth, mask, factor_depth, depth_min, depth_max)
+    vpix, cnt = valid if valid is not None else valid_pixels(depth, mask, factor_depth, depth_min, depth_max)
     if positions is not None:
         positions = positions.to(device=dev, dtype=torch.int32).contiguous()
         if positions.shape != (B, n):
             raise RuntimeError("positions must be (B, num_point)")
     elif random_words is None:
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(0 if seed is None else int(seed))
-        r64 = torch.randint(0, 2 ** 32, (B, n), dtype=torch.int64, device=dev, generator=gen)
-        random_words = torch.where(r64 >= 2 ** 31, r64 - 2 ** 32, r64).to(torch.int32)       # the same 32 bits, as int32
-    if random_words is not None:
+        if keys is None:
+            keys = draw_keys(0 if seed is None else seed, B, dev)
+        positions = draw_positions(cnt, n, keys)
+    if random_words is not None and positions is None:
         random_words = random_words.to(device=dev).contiguous()
         if random_words.dtype not in (torch.int32, torch.uint32) or random_words.shape != (B, n):
             raise RuntimeError("random_words must be (B, num_point) 32-bit integers")
@@ -271,12 +336,19 @@ def sort_and_nms(grasps, counts=None, drop_mask=None, translation_thresh=0.03, r
 
 
 def grasp_pipeline(clouds, grasps, counts, voxel_size=0.01, approach_dist=0.05, collision_thresh=0.01,
-                   translation_thresh=0.03, rotation_thresh=30.0 / 180.0 * np.pi, nms=True, n_valid=None):
+                   translation_thresh=0.03, rotation_thresh=30.0 / 180.0 * np.pi, nms=True, n_valid=None, return_status=False,
+                   check=False):
     """What test.py:88-96 / demo_pointcloud.py:228-249 run on the host per scene after pred_decode -- voxel down-sample of the
     scene, ModelFreeCollisionDetector.detect, drop the collisions, sort by score (+ NMS) -- for the whole batch on the device:
     ~12 launches, no host read, no allocation besides torch's caching allocator, hipGraph-capturable.
-    clouds (B,N,3) f32, grasps (B,M,17) + counts (B,) as GraspNet.decode_padded() leaves them ->
-    (rows (B,M,17) sorted by score with zero padding, kept (B,) i32, collision mask (B,M) bool)."""
+    clouds (B,N,3) f32: the SCENE the grasps are checked against -- the reference uses the raw masked cloud (test.py:92
+    return_raw_cloud=True, demo.py:481 cloud_masked; masked_cloud() builds it on the device), not the num_point points sampled
+    for the network; n_valid (B,) i32: rows of `clouds` past it are padding.  grasps (B,M,17) + counts (B,) as
+    GraspNet.decode_padded() leaves them ->
+    (rows (B,M,17) sorted by score with zero padding, kept (B,) i32, collision mask (B,M) bool [, voxel status (B,) i32]).
+    return_status: also return the voxel step's per-scene status, on the device (0 ok; 1 = the scene spans more than 2^21
+    voxels on an axis -- e.g. one far outlier: its points were left out and every grasp comes back collision-free; 2 = table
+    overflow); check=True reads it back (one sync) and raises instead."""
     if not (clouds.is_cuda and grasps.is_cuda):
         raise RuntimeError("CPU not supported")
     clouds = clouds.to(torch.float32).contiguous()
@@ -289,10 +361,47 @@ def grasp_pipeline(clouds, grasps, counts, voxel_size=0.01, approach_dist=0.05, 
     out = torch.empty_like(grasps)
     oc = torch.empty((B,), dtype=torch.int32, device=dev)
     cm = torch.empty((B, M), dtype=torch.uint8, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
     nv = None if n_valid is None else n_valid.to(device=dev, dtype=torch.int32).contiguous()
     with torch.cuda.device(dev):      # ONE C call: voxel down-sample -> collision detect -> sort (+ NMS)
         L.check(lib.gn_grasp_postprocess(clouds.data_ptr(), L.ptr(nv), B, n, grasps.data_ptr(), L.ptr(counts), M, float(voxel_size),
                                          float(approach_dist), float(collision_thresh), float(translation_thresh),
                                          float(rotation_thresh), 1 if nms else 0, ws.data_ptr(), out.data_ptr(), oc.data_ptr(),
-                                         cm.data_ptr(), None, _stream(grasps)), "grasp_postprocess")
+                                         cm.data_ptr(), status.data_ptr(), _stream(grasps)), "grasp_postprocess")
+    if check:
+        e = int(status.max().item()) if B else 0
+        if e:
+            raise RuntimeError("grasp_pipeline: a scene's voxel grid exceeds 2^21 cells per axis or its table overflowed (code %d): "
+                               "its points were left out of the collision check" % e)
+    if return_status:
+        return out, oc, cm.view(torch.bool), status
     return out, oc, cm.view(torch.bool)
+
+
+def image_to_grasps(net, depth, mask, intrinsics, num_point=20000, keys=None, seed=None, positions=None, post=None,
+                    scene_points=None, depth_min=0.0, depth_max=float("inf")):
+    """A caller's whole loop body (demo.py:449-499, test.py:82-103) for a batch of depth images, entirely on the device:
+        depth (B,H,W) u16 + workspace mask  ->  valid pixels (mask & depth > 0)  ->  num_point of them drawn (without
+        replacement)  ->  cloud  ->  GraspNet.forward  ->  pred_decode  ->  [post: voxel down-sample of the RAW masked cloud,
+        collision filter, sort + NMS]
+    intrinsics = (fx, fy, cx, cy, factor_depth); keys (B,4) / seed: the device's draw (draw_positions), or positions (B,num_point):
+    the caller's own (with the reference's idxs the cloud is the reference's bit for bit).  post: None or a dict of
+    grasp_pipeline() keyword arguments; scene_points: rows of the raw masked cloud kept per image (default H*W).
+    -> dict(end_points, grasps (B,M,17), counts (B,), cloud (B,num_point,3), n_valid_pixels (B,)
+            [, final_rows, kept, collision_mask, voxel_status, scene (B,scene_points,3), scene_n_valid (B,)]).
+    ~25 + ~20 launches, no host read, no allocation besides torch's caching allocator: hipGraph-capturable
+    (GraphedGraspNet(front=...))."""
+    fx, fy, cx, cy, factor = (float(v) for v in intrinsics)
+    if depth.dim() == 2:
+        depth, mask = depth.unsqueeze(0), (None if mask is None else mask.unsqueeze(0))
+    valid = valid_pixels(depth, mask, factor, depth_min, depth_max)
+    cloud, cnt = depth_to_cloud_masked(depth, mask, fx, fy, cx, cy, factor, num_point, positions=positions, keys=keys, seed=seed,
+                                       depth_min=depth_min, depth_max=depth_max, valid=valid)
+    ep = net({"point_clouds": cloud})
+    grasps, counts = net.decode_padded(ep)
+    out = {"end_points": ep, "grasps": grasps, "counts": counts, "cloud": cloud, "n_valid_pixels": cnt}
+    if post is not None:
+        scene, scene_n = masked_cloud(depth, mask, fx, fy, cx, cy, factor, scene_points, depth_min, depth_max, valid=valid)
+        rows, kept, cm, status = grasp_pipeline(scene, grasps, counts, n_valid=scene_n, return_status=True, **post)
+        out.update(final_rows=rows, kept=kept, collision_mask=cm, voxel_status=status, scene=scene, scene_n_valid=scene_n)
+    return out

@@ -431,6 +431,21 @@ int gn_depth_sample_cloud(const uint16_t *depth, int b, int h, int w, double fx,
                           double factor_depth, const int32_t *valid_pix, const int32_t *count, const int32_t *positions,
                           const uint32_t *random_words, int n, float *out, int32_t *out_pix, gn_stream_t stream);
 
+/* cloud_masked itself (dataset/graspnet_dataset.py:133 / demo.py:455 `cloud[mask]`): out (B,nmax,3) f32, row i = the cloud point
+ * of valid pixel i for i < min(count[b], nmax), zero rows behind; out_count (B) = min(count, nmax) (may be NULL).  This is the
+ * scene the reference hands to ModelFreeCollisionDetector (test.py:92-96 return_raw_cloud, demo.py:481) -- NOT the num_point
+ * points sampled for the network: feed it to gn_grasp_postprocess with n_valid = out_count. */
+int gn_depth_masked_cloud(const uint16_t *depth, int b, int h, int w, double fx, double fy, double cx, double cy,
+                          double factor_depth, const int32_t *valid_pix, const int32_t *count, int nmax, float *out,
+                          int32_t *out_count, gn_stream_t stream);
+/* The draw of dataset/graspnet_dataset.py:139-145 / demo.py:458-463 on the device: positions (B,n) into the valid list.
+ * count[b] >= n: n DISTINCT positions (np.random.choice(..., replace=False)) = the first n values of a keyed pseudo-random
+ * permutation of [0, count) (4-round Feistel network, cycle-walked; csrc/frontend.hip); count[b] < n: arange(count) followed
+ * by n - count draws with replacement, as the reference does.  keys (B,4) u32: any words (e.g. hashes of a seed and the
+ * image number); equal keys give equal draws.  numpy's own stream cannot be reproduced -- parity is on the distribution
+ * (distinctness, range, arange prefix) and on the integer restatement in oracle/post_oracle.py. */
+int gn_depth_draw_positions(const int32_t *count, const uint32_t *keys, int b, int n, int32_t *positions, gn_stream_t stream);
+
 /* open3d voxel_down_sample as used by utils/collision_detector.py:32-35 (un-vendored; restated:
  * origin = min_bound - voxel/2, voxel index = floor((p-origin)/voxel), output = mean of members in
  * float64), for a whole batch of clouds in one call, no host read, DETERMINISTIC: the voxels of a cloud

@@ -35,6 +35,61 @@ def masked_cloud_sample(depth, mask, fx, fy, cx, cy, scale, idxs, depth_min=0.0,
     return cloud_masked[np.asarray(idxs)].astype(np.float32), int(len(cloud_masked))
 
 
+def _hash32(x):
+    """lowbias32 on uint32 arrays (csrc/frontend.hip fe_hash32)"""
+    x = np.asarray(x, dtype=np.uint64) & 0xffffffff
+    x ^= x >> 16
+    x = (x * 0x7feb352d) & 0xffffffff
+    x ^= x >> 15
+    x = (x * 0x846ca68b) & 0xffffffff
+    x ^= x >> 16
+    return x
+
+
+def draw_keys(seed, nimages):
+    """(nimages, 4) uint32 round keys from a seed: key[b][r] = hash32(seed + 0x9e3779b9 * (4 b + r + 1)) -- what
+    graspnet_amd.postprocess.draw_keys computes (host side, both)"""
+    b = np.arange(nimages, dtype=np.uint64)[:, None]
+    r = np.arange(4, dtype=np.uint64)[None, :]
+    return _hash32((np.uint64(int(seed) & 0xffffffff) + 0x9e3779b9 * (4 * b + r + 1)) & 0xffffffff).astype(np.uint32)
+
+
+def draw_positions(count, keys, n):
+    """numpy restatement of csrc/frontend.hip fe_draw_kernel -- the device's stand-in for dataset/graspnet_dataset.py:139-145 /
+    demo.py:458-463: count >= n: n DISTINCT positions (a keyed Feistel permutation of [0, count), cycle-walked), like
+    np.random.choice(count, n, replace=False); count < n: arange(count) then draws with replacement, like the reference.
+    count (B,), keys (B,4) uint32 -> (B,n) int32.  Integer arithmetic only: bit-identical to the kernel."""
+    count = np.asarray(count).reshape(-1)
+    keys = np.asarray(keys, dtype=np.uint32).reshape(-1, 4)
+    out = np.zeros((len(count), n), np.int32)
+    i = np.arange(n, dtype=np.uint64)
+    for b, cnt in enumerate(int(c) for c in count):
+        k = [np.uint64(v) for v in keys[b]]
+        if cnt <= 0:
+            continue
+        if cnt < n:
+            w = _hash32(((i * 0x9e3779b9) & 0xffffffff) ^ k[0])
+            out[b] = np.where(i < cnt, i, (w * np.uint64(cnt)) >> 32).astype(np.int32)
+            continue
+        half = 1
+        while (1 << (2 * half)) < cnt:
+            half += 1
+        hm = np.uint64((1 << half) - 1)
+        x = i.copy()
+        todo = np.ones(n, bool)
+        for _ in range(1 << (2 * half)):
+            l, r = x >> np.uint64(half), x & hm
+            for kk in k:
+                l, r = r, l ^ (_hash32(r ^ kk) & hm)
+            y = (l << np.uint64(half)) | r
+            x = np.where(todo, y, x)
+            todo &= x >= cnt
+            if not todo.any():
+                break
+        out[b] = x.astype(np.int32)
+    return out
+
+
 def voxel_down_sample(points, voxel_size):
     pts = np.asarray(points, dtype=np.float64)
     origin = pts.min(axis=0) - voxel_size * 0.5

@@ -87,7 +87,30 @@ def test_front_end_on_the_device_matches_the_reference_formula(golden_dir):
     for b in range(B):
         m = ((mask[b] != 0) & (depth[b] > 0)).reshape(-1)
         assert m[p1[b]].all()
-        assert len(np.unique(p1[b])) > 0.5 * min(n, counts[b])
+        # the seeded draw is WITHOUT replacement where the image has enough valid pixels (graspnet_dataset.py:140,
+        # np.random.choice(..., replace=False)): no duplicated point reaches the sampler
+        assert len(np.unique(p1[b])) == min(n, counts[b])
+    # ... and equals the integer restatement of the keyed permutation (oracle/post_oracle.py draw_positions) bit for bit
+    keys = PO.draw_keys(11, B)
+    assert np.array_equal(P.draw_keys(11, B).numpy().view(np.uint32), keys)
+    want_pos = PO.draw_positions(np.array(counts), keys, n)
+    got_pos = P.draw_positions(cnt, n, P.draw_keys(11, B, "cuda")).cpu().numpy()
+    assert np.array_equal(got_pos, want_pos)
+    for b in range(B):
+        v = np.nonzero(((mask[b] != 0) & (depth[b] > 0)).reshape(-1))[0]
+        assert np.array_equal(p1[b], v[want_pos[b]])
+    # random words the caller brings: with replacement (documented), still only valid pixels
+    words = torch.from_numpy(rng.integers(0, 2 ** 32, size=(B, n), dtype=np.uint64).astype(np.uint32).view(np.int32)).cuda()
+    _, _, pw = P.depth_to_cloud_masked(d, mk, fx, fy, cx, cy, scale, n, random_words=words, return_pix=True)
+    pw = pw.cpu().numpy()
+    for b in range(B):
+        assert ((mask[b] != 0) & (depth[b] > 0)).reshape(-1)[pw[b]].all()
+    # the raw masked cloud (the scene of the collision check): numpy's cloud[mask], zero rows behind it
+    sc, sn = P.masked_cloud(d, mk, fx, fy, cx, cy, scale, max_points=20000)
+    assert sn.cpu().tolist() == [min(c, 20000) for c in counts]
+    for b in range(B):
+        full, nvalid = PO.masked_cloud_sample(depth[b], mask[b], fx, fy, cx, cy, scale, np.arange(min(counts[b], 20000)))
+        assert np.array_equal(sc[b, :int(sn[b])].cpu().numpy(), full) and not sc[b, int(sn[b]):].any()
     assert np.array_equal(p1[2, :counts[2]], np.nonzero(((mask[2] != 0) & (depth[2] > 0)).reshape(-1))[0])
     # an image without a valid pixel: zeros, count 0
     z, cz = P.depth_to_cloud_masked(torch.zeros_like(d[0]), None, fx, fy, cx, cy, scale, 64, seed=1)
@@ -279,16 +302,143 @@ def test_full_pipeline_is_graph_capturable_and_sync_free(state_dict):
     want_rows, want_kept, want_cm = P.grasp_pipeline(clouds, g, c)
     torch.cuda.synchronize()
     gnet = GraphedGraspNet(net, batch=4, points=20000, post=dict(voxel_size=0.01, approach_dist=0.05, collision_thresh=0.01))
-    _, _, _, rows, kept, cm = gnet(clouds)
+    _, _, _, rows, kept, cm, status = gnet(clouds)
     torch.cuda.synchronize()
-    assert torch.equal(kept, want_kept) and torch.equal(cm, want_cm) and torch.equal(rows, want_rows)
+    assert torch.equal(kept, want_kept) and torch.equal(cm, want_cm) and torch.equal(rows, want_rows) and not status.any()
     r1, k1 = rows.clone(), kept.clone()
     gnet(S.make_batch(2000, 4, 20000, "uniform").cuda())
-    _, _, _, rows, kept, cm = gnet(clouds)
+    _, _, _, rows, kept, cm, status = gnet(clouds)
     torch.cuda.synchronize()
     assert torch.equal(rows, r1) and torch.equal(kept, k1)
     k = kept.cpu().tolist()
     assert all(0 < k[b] < int(c[b]) for b in range(4))
+
+
+@pytest.mark.parametrize("count,n", [(300000, 20000), (20000, 20000), (20001, 20000), (65536, 4096), (65537, 4096), (7, 7), (2, 1),
+                                     (150, 500), (1, 64), (921600, 20000)])
+def test_device_draw_is_a_permutation_prefix(count, n):
+    """gn_depth_draw_positions at the layout boundaries of its Feistel network (powers of four, one past them, tiny counts, a full
+    720 x 1280 image): count >= n gives n distinct positions in range, equal to the numpy restatement; count < n gives
+    arange(count) first; different keys give different draws; every position of [0, count) is reachable (count = n: a
+    permutation)"""
+    from graspnet_amd import postprocess as P
+    from oracle import post_oracle as PO
+    cnt = torch.tensor([count, count], dtype=torch.int32, device="cuda")
+    keys = P.draw_keys(77, 2, "cuda")
+    got = P.draw_positions(cnt, n, keys).cpu().numpy()
+    want = PO.draw_positions([count, count], PO.draw_keys(77, 2), n)
+    assert np.array_equal(got, want)
+    assert got.min() >= 0 and got.max() < count
+    if count >= n:
+        assert len(np.unique(got[0])) == n and len(np.unique(got[1])) == n
+        if count == n:
+            assert np.array_equal(np.sort(got[0]), np.arange(n))
+        if n > 16:
+            assert not np.array_equal(got[0], got[1])
+    else:
+        assert np.array_equal(got[0, :count], np.arange(count))
+
+
+def test_image_to_grasps_one_replay_matches_the_fixture(golden_dir, state_dict):
+    """Round-4 VERDICT item 5: depth u16 + mask -> top grasps as ONE leg (demo.py:449-499 / test.py:82-103 on the device, one
+    hipGraph): the example scene of the reference (doc/example_data; fixture = the reference's own pixel draw + the cloud its
+    create_point_cloud_from_depth_image gives) through GraphedGraspNet(front=..., post=...) with the committed draw as
+    `positions` -- the cloud is the fixture's bit for bit, the samplers' indices the golden ones, the decoded rows the golden
+    rows (same rule as test_example_scene_config5); the collision filter runs against the RAW masked cloud (every valid pixel,
+    not the 20 000 sampled ones), whose voxel grid equals the numpy restatement's on the same pixels; the eager call and two
+    replays agree bit for bit; the device's own draw (seed) gives 20 000 distinct valid pixels"""
+    import parity_util as PU
+    from graspnet_amd import GraspNet, GraphedGraspNet, postprocess as P
+    from oracle import post_oracle as PO
+    z = np.load(golden_dir + "/example_scene_n20000.npz")
+    h, w = int(z["shape"][0]), int(z["shape"][1])
+    intr = tuple(float(v) for v in z["intrinsics"])
+    # the fixture holds the reference's picked pixels only: an image with those pixels and, around them, 30 000 more valid
+    # pixels of plausible depth (the raw masked cloud is larger than the sample, as in the reference's scene)
+    rng = np.random.default_rng(9)
+    depth = np.zeros(h * w, np.uint16)
+    extra = rng.choice(np.setdiff1d(np.arange(h * w), z["pix"]), 30000, replace=False)
+    depth[extra] = rng.integers(int(z["depth_at_pix"].min()), int(z["depth_at_pix"].max()) + 1, size=30000).astype(np.uint16)
+    depth[z["pix"]] = z["depth_at_pix"]
+    mask = (depth > 0).astype(np.uint8)
+    valid = np.nonzero(depth > 0)[0]
+    positions = np.searchsorted(valid, z["pix"]).astype(np.int32)          # the reference's draw, as positions into cloud[mask]
+    d = torch.from_numpy(depth.reshape(1, h, w).view(np.int16)).cuda()
+    mk = torch.from_numpy(mask.reshape(1, h, w)).cuda()
+    net = GraspNet().load_state_dict(state_dict)
+    post = dict(voxel_size=0.01, approach_dist=0.05, collision_thresh=0.2)
+    out = P.image_to_grasps(net, d, mk, intr, num_point=20000, positions=torch.from_numpy(positions).reshape(1, -1), post=post,
+                            scene_points=60000)
+    torch.cuda.synchronize()
+    assert np.array_equal(out["cloud"][0].cpu().numpy(), z["cloud"])                  # == the reference's function on its draw
+    assert int(out["n_valid_pixels"][0]) == len(valid) == int(out["scene_n_valid"][0]) and not out["voxel_status"].any()
+    ep = out["end_points"]
+    assert np.array_equal(ep["sa1_inds"].cpu().numpy(), z["sa1_inds"]) and np.array_equal(ep["sa2_inds"].cpu().numpy(), z["sa2_inds"])
+    n = int(out["counts"][0])
+    rows = PU.compare_rows([out["grasps"][0, :n]], [torch.from_numpy(z["grasps"])])
+    assert rows["score_max"] <= rows["score_limit"] and rows["width_max"] <= 1e-5, rows
+    assert rows["class_flips"] <= 2 and rows["objectness_flips"] <= 2 and rows["rows"] >= len(z["grasps"]) - 4, rows
+    # the scene of the collision check is the raw masked cloud: numpy's cloud[mask] on the same image, voxel for voxel
+    cloud_all, _ = PO.masked_cloud_sample(depth.reshape(h, w), mask.reshape(h, w), *intr, np.arange(len(valid)))
+    assert np.array_equal(out["scene"][0, :len(valid)].cpu().numpy(), cloud_all)
+    scene_np = PO.voxel_down_sample_ordered(cloud_all, 0.01)
+    garr = out["grasps"][0, :n].cpu().numpy()
+    wcm, _, _ = PO.collision_detect(scene_np, garr, approach_dist=0.05, collision_thresh=0.2, voxel_size=0.01)
+    assert np.array_equal(out["collision_mask"][0, :n].cpu().numpy(), wcm)
+    keep = PO.nms_grasp(garr[~wcm], 0.03, 30.0 / 180.0 * np.pi)
+    assert int(out["kept"][0]) == len(keep) and np.array_equal(out["final_rows"][0, :len(keep)].cpu().numpy(), keep)
+    # against the sampled cloud as scene (what round 4's post= did): the raw scene fills more voxels -> at least as many collisions
+    _, _, cm_s = P.grasp_pipeline(out["cloud"], out["grasps"], out["counts"], **post)
+    assert int(out["collision_mask"].sum()) >= int(cm_s.sum())
+    # ONE hipGraph replay == the eager call, twice
+    gnet = GraphedGraspNet(net, batch=1, points=20000, post=post,
+                           front=dict(height=h, width=w, intrinsics=intr, scene_points=60000))
+    # (the graph draws on the device: give it the same draw by keys -> compare against an eager call with the same keys)
+    keys = P.draw_keys(5, 1, "cuda")
+    eager = P.image_to_grasps(net, d, mk, intr, num_point=20000, keys=keys, post=post, scene_points=60000)
+    e_rows, e_kept, e_cloud = eager["final_rows"].clone(), eager["kept"].clone(), eager["cloud"].clone()
+    for _ in range(2):
+        got = gnet(d, mk, keys=keys)
+        torch.cuda.synchronize()
+        assert torch.equal(got["cloud"], e_cloud) and torch.equal(got["kept"], e_kept) and torch.equal(got["final_rows"], e_rows)
+        gnet(torch.full_like(d, 700), None, seed=3)              # another image in between
+    pix_cloud = got["cloud"][0].cpu().numpy()
+    assert len(np.unique(pix_cloud, axis=0)) == 20000            # the device's draw: 20 000 distinct pixels
+    assert 0 < int(e_kept[0]) <= 1024
+
+
+def test_collision_filter_uses_the_callers_scene_and_reports_voxel_status(state_dict):
+    """PipelinedGraspNet / GraphedGraspNet(post=) check the grasps against a SEPARATE scene cloud (the
+    reference: the raw masked cloud, test.py:92 / demo.py:481) when one is given, equal to grasp_pipeline on that scene; and a
+    scene whose voxel grid cannot be built (one far outlier stretches it beyond 2^21 cells) says so in `voxel_status` (and
+    raises with check=True) instead of returning every grasp collision-free in silence"""
+    from graspnet_amd import GraspNet, GraphedGraspNet, PipelinedGraspNet, postprocess as P, synthetic as S
+    net = GraspNet().load_state_dict(state_dict)
+    args = dict(voxel_size=0.01, approach_dist=0.05, collision_thresh=0.01)
+    raw = S.make_batch(4100, 2, 60000, "uniform").cuda()                     # the "raw" scenes: 60 000 points
+    x = raw[:, :20000].contiguous()                                          # the network's sample of them
+    nvalid = torch.tensor([60000, 45000], dtype=torch.int32, device="cuda")
+    g, c = net.decode_padded(net({"point_clouds": x}))
+    rows, kept, cm, st = P.grasp_pipeline(raw, g, c, n_valid=nvalid, return_status=True, **args)
+    _, kept_s, cm_s = P.grasp_pipeline(x, g, c, **args)
+    assert not st.any() and int(cm.sum()) > int(cm_s.sum())                  # a denser scene collides with more grasps
+    pipe = PipelinedGraspNet(net, depth=2, post=args)
+    t = pipe.submit(x, scene=raw, scene_n_valid=nvalid)
+    t.result()
+    assert torch.equal(t.final_rows, rows) and torch.equal(t.kept, kept) and torch.equal(t.collision_mask, cm) and not t.voxel_status.any()
+    gnet = GraphedGraspNet(net, batch=2, points=20000, post=args, scene_points=60000)
+    out = gnet(x, scene=raw, scene_n_valid=nvalid)
+    torch.cuda.synchronize()
+    assert torch.equal(out[3], rows) and torch.equal(out[4], kept) and torch.equal(out[5], cm) and not out[6].any()
+    out = gnet(x)                                                            # no scene given: the sampled cloud, as before
+    torch.cuda.synchronize()
+    assert torch.equal(out[4], kept_s)
+    bad = raw.clone()
+    bad[1, 7, 0] = -3.0e5                                                    # one far outlier in scene 1
+    _, _, cm_b, st_b = P.grasp_pipeline(bad, g, c, n_valid=nvalid, return_status=True, **args)
+    assert st_b.cpu().tolist() == [0, 1] and torch.equal(cm_b[0], cm[0])
+    with pytest.raises(RuntimeError, match="voxel grid"):
+        P.grasp_pipeline(bad, g, c, n_valid=nvalid, check=True, **args)
 
 
 def test_pipelined_batches_with_post_processing(state_dict):

@@ -121,7 +121,8 @@ void set_error(const char *fmt, ...);
 static inline hipStream_t as_stream(gn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // grad_det.hip: ascending order inside every destination's segment of an inverted index list
-int seg_order(const int32_t *idx, int b, int n, int ne, const int32_t *off, int32_t *list, hipStream_t s);
+// skip (b, n) u8 or NULL: destinations flagged there keep their arbitrary (ticket) order
+int seg_order(const int32_t *idx, int b, int n, int ne, const int32_t *off, int32_t *list, hipStream_t s, const uint8_t *skip = nullptr);
 
 // ---- wave64 DPP reductions (row = 16 lanes).  dpp_ctrl encodings: quad_perm 0x00-0xFF,
 // row_half_mirror 0x141, row_mirror 0x140.

@@ -72,9 +72,11 @@ __global__ __launch_bounds__(256) void inv_fill_kernel(const int32_t *__restrict
   list[(size_t)b * ne + off[(size_t)b * (n + 1) + a] + slot] = e;
 }
 
-// one wave per 64 consecutive destinations
+// one wave per 64 consecutive destinations.  skip (may be NULL): destinations whose sum does not depend on the order of its
+// entries (post.hip: a voxel whose float64 partial sums are all exact) keep their ticket order
 __global__ __launch_bounds__(256) void inv_order_kernel(const int32_t *__restrict__ idx, int n, int ne,
-                                                        const int32_t *__restrict__ off, int32_t *__restrict__ list) {
+                                                        const int32_t *__restrict__ off, int32_t *__restrict__ list,
+                                                        const uint8_t *__restrict__ skip) {
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int a0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void inv_order_kernel(const int32_t *__restric
   const int32_t *o = off + (size_t)b * (n + 1);
   int32_t *l = list + (size_t)b * ne;
   const int lo = a < n ? o[a] : 0, hi = a < n ? o[a + 1] : 0;
-  const int s = hi - lo;
+  const int s = (a < n && skip && skip[(size_t)b * n + a]) ? 0 : hi - lo;
   if (s > 1 && s <= SORT_MAX) {
     for (int i = lo + 1; i < hi; ++i) {
       const int v = l[i];
@@ -97,7 +99,8 @@ __global__ __launch_bounds__(256) void inv_order_kernel(const int32_t *__restric
 // the long segments, in a launch of their own: its 64 KB of LDS would otherwise cap the common case above (every segment
 // <= 64 entries, no LDS at all) at two workgroups per CU.  A wave without a long segment leaves at once.
 __global__ __launch_bounds__(256) void inv_order_long_kernel(const int32_t *__restrict__ idx, int n, int ne,
-                                                             const int32_t *__restrict__ off, int32_t *__restrict__ list) {
+                                                             const int32_t *__restrict__ off, int32_t *__restrict__ list,
+                                                             const uint8_t *__restrict__ skip) {
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int a0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void inv_order_long_kernel(const int32_t *__re
   const int32_t *o = off + (size_t)b * (n + 1);
   int32_t *l = list + (size_t)b * ne;
   const int lo = a < n ? o[a] : 0, hi = a < n ? o[a + 1] : 0;
-  const int s = hi - lo;
+  const int s = (a < n && skip && skip[(size_t)b * n + a]) ? 0 : hi - lo;
   if (!__ballot(s > SORT_MAX)) return;
   // 64 < s <= WSORT_MAX: the wave sorts the segment in LDS (s log^2 s / 64 compare-exchange steps; the ballot rebuild
   // below costs ne / 64 steps per destination whatever s is: 2 048 at SA1's 2048 x 64 entries)
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256) void grad_sum_kernel(const float *__restrict__
   }
 }
 
-int seg_order(const int32_t *idx, int b, int n, int ne, const int32_t *off, int32_t *list, hipStream_t s);
+int seg_order(const int32_t *idx, int b, int n, int ne, const int32_t *off, int32_t *list, hipStream_t s, const uint8_t *skip);
 
 struct InvWs { int32_t *off, *cursor, *list; };
 
@@ -206,7 +209,7 @@ static int invert(const int32_t *idx, int b, int n, long ne, void *workspace, In
     hipLaunchKernelGGL(inv_count_kernel, ge, dim3(256), 0, s, idx, n, (int)ne, w.off);
     hipLaunchKernelGGL(inv_scan_kernel, dim3(b), dim3(1024), 0, s, n, w.off);
     hipLaunchKernelGGL(inv_fill_kernel, ge, dim3(256), 0, s, idx, n, (int)ne, w.off, w.cursor, w.list);
-    if (int rc = seg_order(idx, b, n, (int)ne, w.off, w.list, s)) return rc;
+    if (int rc = seg_order(idx, b, n, (int)ne, w.off, w.list, s, nullptr)) return rc;
   }
   *out = w;
   return GN_OK;
@@ -214,11 +217,11 @@ static int invert(const int32_t *idx, int b, int n, long ne, void *workspace, In
 
 // off (b, n+1) / list (b, ne) as the inversion leaves them after its fill pass, idx (b, ne) the destination of every entry:
 // puts each destination's segment of `list` in ascending order (shared with the voxel down-sample of post.hip)
-int seg_order(const int32_t *idx, int b, int n, int ne, const int32_t *off, int32_t *list, hipStream_t s) {
+int seg_order(const int32_t *idx, int b, int n, int ne, const int32_t *off, int32_t *list, hipStream_t s, const uint8_t *skip) {
   if (b <= 0 || n <= 0 || ne <= 0) return GN_OK;
   dim3 go((unsigned)((n + 255) / 256), b);
-  hipLaunchKernelGGL(inv_order_kernel, go, dim3(256), 0, s, idx, n, ne, off, list);
-  if (ne > SORT_MAX) hipLaunchKernelGGL(inv_order_long_kernel, go, dim3(256), 0, s, idx, n, ne, off, list);
+  hipLaunchKernelGGL(inv_order_kernel, go, dim3(256), 0, s, idx, n, ne, off, list, skip);
+  if (ne > SORT_MAX) hipLaunchKernelGGL(inv_order_long_kernel, go, dim3(256), 0, s, idx, n, ne, off, list, skip);
   GN_CHECK_LAUNCH("seg_order");
   return GN_OK;
 }

@@ -17,6 +17,8 @@
 //
 // The reference does these in numpy / open3d on the host after a device->host copy of the grasps
 // (test.py:88-96); its README calls the collision check the slow step (README.md:72).
+#include <stdlib.h>
+
 #include "gn_common.h"
 
 namespace gn {
@@ -52,8 +54,19 @@ __global__ __launch_bounds__(256) void depth_to_cloud_kernel(const uint16_t *__r
 //     round-3 form, were neither).
 // workspace per call (b clouds of n points, S = table slots per cloud):
 //   keys u64 [b][S] | first u32 [b][S]            <- one 0xff memset
-//   cnt i32 [b][S] | cursor i32 [b][S] | hdr [b]  <- one zero memset
-//   srank i32 [b][S] | pslot i32 [b][n] | vidx i32 [b][n] | off i32 [b][n+1] | list i32 [b][n]
+//   cnt i32 [b][S] | cursor i32 [b][S] | sflag u32 [b][S] | hdr [b]  <- one zero memset
+//   srank i32 [b][S] | pslot i32 [b][n] | vidx i32 [b][n] | off i32 [b][n+1] | list i32 [b][n] | skip u8 [b][n]
+// Round 5 -- scenes of a whole camera frame (the reference's callers hand the detector the RAW masked cloud: 3-5 x 10^5
+// points, ~100 per 1 cm voxel on a table top, where round 4 measured 2.8 ms per batch of 8: 0.87 + 0.33 ms of it putting member
+// lists of 60-130 entries in ascending order, 0.63 + 0.25 ms in the two one-workgroup-per-cloud passes):
+//   * ORDER ONLY WHERE IT MATTERS.  A float64 sum of float32 values does not depend on the order of its terms as long as every
+//     partial sum is exact, i.e. as long as  (largest exponent) + 1 + ceil(log2 members) - (smallest exponent - 23) <= 53.
+//     A voxel's coordinates on an axis lie in an interval known from its index, so the exponents are bounded from the interval
+//     -- except where the interval holds zero, where the smallest exponent is measured (an integer atomic max per such
+//     point, sflag).  The leader of a voxel decides `exact`, and seg_order() leaves exact voxels in ticket order: on camera
+//     data that is every voxel (x = (col - cx) z / fx is never closer to zero than ~1e-4), and the result is STILL bit-identical
+//     to the sequential restatement by construction -- voxels that fail the test are ordered as before.
+//   * the min-bound and ranking passes run on (chunks x clouds) workgroups beyond 65 536 points (two-level reduce / scan).
 // ------------------------------------------------------------------------------------------------
 struct VoxelHeader {
   double minb[3];
@@ -88,6 +101,44 @@ __global__ __launch_bounds__(1024) void voxel_minbound_kernel(const float *__res
   }
 }
 
+// beyond 65 536 points: (chunks x clouds) workgroups reduce 16 384 points each into scratch, one small pass folds them
+constexpr int VOX_CHUNK = 16384;
+__global__ __launch_bounds__(1024) void voxel_minbound_part_kernel(const float *__restrict__ pts, const int32_t *__restrict__ n_valid,
+                                                                   int n, int nchunk, float *__restrict__ part) {
+  __shared__ float s[3][16];
+  const int b = blockIdx.y, ck = blockIdx.x;
+  pts += (size_t)b * n * 3;
+  const int nv = n_valid ? min(max(n_valid[b], 0), n) : n;
+  float m[3] = {INFINITY, INFINITY, INFINITY};
+  const int hi = min(nv, (ck + 1) * VOX_CHUNK);
+  for (int i = ck * VOX_CHUNK + threadIdx.x; i < hi; i += 1024) {
+    const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+    if (finite3(x, y, z)) { m[0] = fminf(m[0], x); m[1] = fminf(m[1], y); m[2] = fminf(m[2], z); }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int a = 0; a < 3; ++a) {
+    const float v = -wave_max(-m[a]);
+    if (lane == 0) s[a][wave] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float v = s[threadIdx.x][0];
+    for (int wv = 1; wv < 16; ++wv) v = fminf(v, s[threadIdx.x][wv]);
+    part[((size_t)b * nchunk + ck) * 3 + threadIdx.x] = v;
+  }
+}
+__global__ __launch_bounds__(64) void voxel_minbound_fold_kernel(const float *__restrict__ part, int nchunk,
+                                                                 VoxelHeader *__restrict__ hdr, int32_t *__restrict__ status) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  for (int a = 0; a < 3; ++a) {
+    float m = INFINITY;
+    for (int c = lane; c < nchunk; c += 64) m = fminf(m, part[((size_t)b * nchunk + c) * 3 + a]);
+    m = -wave_max(-m);
+    if (lane == 0) hdr[b].minb[a] = (double)m;
+  }
+  if (lane == 0) status[b] = 0;
+}
+
 __device__ __forceinline__ unsigned long long hash64(unsigned long long k) {
   k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
   return k;
@@ -95,12 +146,24 @@ __device__ __forceinline__ unsigned long long hash64(unsigned long long k) {
 
 constexpr unsigned long long VOXEL_EMPTY = ~0ULL;
 
+// does voxel vi's interval [origin + vi voxel, + voxel) on an axis hold zero, or come within a thousandth of a voxel of it?
+// (then the smallest exponent among its members cannot be bounded from the interval and is measured instead)
+__device__ __forceinline__ bool voxel_holds_zero(double origin, long long vi, double voxel) {
+  const double lo = origin + (double)vi * voxel, hi = lo + voxel;
+  return lo <= voxel * 1e-3 && hi >= -voxel * 1e-3;
+}
+__device__ __forceinline__ int f32_biased_exp(double v) {       // biased exponent of v rounded to float32, subnormals as 1
+  const unsigned be = (__float_as_uint((float)fabs(v)) >> 23) & 0xffu;
+  return (int)max(be, 1u);
+}
+
 // one thread per point: its voxel's table slot; the slot's member count and lowest member index
 __global__ __launch_bounds__(256) void voxel_insert_kernel(const float *__restrict__ pts, const int32_t *__restrict__ n_valid,
                                                            int n, double voxel, const VoxelHeader *__restrict__ hdr,
                                                            unsigned long long *__restrict__ keys, unsigned *__restrict__ first,
-                                                           int *__restrict__ cnt, int32_t *__restrict__ pslot,
-                                                           unsigned table_mask, int32_t *__restrict__ status) {
+                                                           int *__restrict__ cnt, unsigned *__restrict__ sflag,
+                                                           int32_t *__restrict__ pslot, unsigned table_mask,
+                                                           int32_t *__restrict__ status) {
   const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
   if (i >= n) return;
   const size_t tb = (size_t)b * (table_mask + 1);
@@ -111,38 +174,93 @@ __global__ __launch_bounds__(256) void voxel_insert_kernel(const float *__restri
   if (i >= nv || !finite3(fx, fy, fz)) { pslot[i] = -1; return; }     // padding / non-finite points belong to no voxel
   const double p[3] = {(double)fx, (double)fy, (double)fz};
   unsigned long long key = 0;
+  unsigned small = 0;      // 255 - (smallest biased float32 exponent among this point's coordinates on axes whose voxel interval holds zero)
   for (int a = 0; a < 3; ++a) {
     const double origin = hdr[b].minb[a] - voxel * 0.5;
     const long long vi = (long long)floor((p[a] - origin) / voxel);
     if (vi < 0 || vi >= (1LL << 21)) { atomicExch(&status[b], 1); pslot[i] = -1; return; }
     key |= (unsigned long long)vi << (21 * a);
-  }
-  unsigned slot = (unsigned)hash64(key) & table_mask;
-  for (unsigned probe = 0; probe <= table_mask; ++probe) {
-    const unsigned long long prev = atomicCAS(&keys[tb + slot], VOXEL_EMPTY, key);
-    if (prev == VOXEL_EMPTY || prev == key) {
-      atomicMin(&first[tb + slot], (unsigned)i);
-      atomicAdd(&cnt[tb + slot], 1);
-      pslot[i] = (int)slot;
-      return;
+    if (voxel_holds_zero(origin, vi, voxel) && p[a] != 0.0) {
+      const unsigned be = (__float_as_uint((float)p[a]) >> 23) & 0xffu;
+      small = max(small, 255u - max(be, 1u));
     }
-    slot = (slot + 1) & table_mask;
   }
-  atomicExch(&status[b], 2);
-  pslot[i] = -1;
+  // RUNS: consecutive points of a camera frame fall into the same voxel ~10 at a time (row-major pixels), so only the first
+  // lane of a run of equal keys goes to the table -- one CAS, one atomicMin (its own index: the run's lowest), one atomicAdd
+  // of the run's length -- and hands the slot to the rest by a shuffle: ~10x fewer atomics on the same address
+  const int lane = threadIdx.x & 63;
+  const unsigned long long prev_key = __shfl_up(key, 1);
+  const unsigned long long act = __ballot(true);                       // lanes that reached this point (the others returned)
+  const bool prev_active = lane > 0 && ((act >> (lane - 1)) & 1ull);
+  const bool head = !(prev_active && prev_key == key);
+  const unsigned long long heads = __ballot(head);
+  const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));      // heads at or below this lane
+  const int head_lane = 63 - __builtin_clzll(below);
+  // the run ends before the next head above this lane, or at the last active lane
+  const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1)) << (lane + 1);
+  const int next_head = above ? __builtin_ctzll(above) : 64;
+  const unsigned long long run_mask = act & ((next_head == 64 ? ~0ull : ((1ull << next_head) - 1ull)) & ~((1ull << head_lane) - 1ull));
+  // (every active lane in [head_lane, next_head) has this key: a lane with another key would have been a head)
+  const int run_len = __popcll(run_mask);
+  unsigned run_small = small;
+  for (int o = 1; o < 64; o <<= 1) {                                   // max of `small` over the run (runs are short: a few steps matter)
+    const unsigned v = __shfl_down(run_small, o);
+    const int src = lane + o;
+    if (src < next_head && src < 64 && ((act >> src) & 1ull)) run_small = max(run_small, v);
+  }
+  int myslot = -1;
+  if (head) {
+    unsigned slot = (unsigned)hash64(key) & table_mask;
+    for (unsigned probe = 0; probe <= table_mask; ++probe) {
+      const unsigned long long prev = atomicCAS(&keys[tb + slot], VOXEL_EMPTY, key);
+      if (prev == VOXEL_EMPTY || prev == key) {
+        atomicMin(&first[tb + slot], (unsigned)i);
+        atomicAdd(&cnt[tb + slot], run_len);
+        if (run_small) atomicMax(&sflag[tb + slot], run_small);
+        myslot = (int)slot;
+        break;
+      }
+      slot = (slot + 1) & table_mask;
+    }
+    if (myslot < 0) atomicExch(&status[b], 2);
+  }
+  pslot[i] = __shfl(myslot, head_lane);
 }
 
 // one thread per point: lc[i] = its voxel's member count if the point is the voxel's lowest member (its "leader"), else 0.
 // Wide on purpose: the two dependent random reads (slot -> first / cnt) are what the ranking pass below must NOT do on its
 // one workgroup per cloud (done there they were 40 serial L2 round trips per wave: 57-70 us).
+// The leader also decides whether its voxel's float64 sums are order-independent (every partial sum exact; see the header of
+// this section) and leaves the verdict in sflag[slot] (1 = exact: seg_order() need not order the member list).
 __global__ __launch_bounds__(256) void voxel_leader_kernel(const int32_t *__restrict__ pslot, const unsigned *__restrict__ first,
-                                                           const int *__restrict__ cnt, int n, unsigned nslots,
-                                                           int32_t *__restrict__ lc) {
+                                                           const int *__restrict__ cnt, const unsigned long long *__restrict__ keys,
+                                                           unsigned *__restrict__ sflag, const VoxelHeader *__restrict__ hdr,
+                                                           double voxel, int n, unsigned nslots, int32_t *__restrict__ lc) {
   const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
   if (i >= n) return;
   const int slot = pslot[(size_t)b * n + i];
   int v = 0;
-  if (slot >= 0 && first[(size_t)b * nslots + slot] == (unsigned)i) v = cnt[(size_t)b * nslots + slot];
+  if (slot >= 0 && first[(size_t)b * nslots + slot] == (unsigned)i) {
+    const size_t s = (size_t)b * nslots + slot;
+    v = cnt[s];
+    const unsigned long long key = keys[s];
+    const unsigned measured = sflag[s];
+    int lg = 0;
+    while ((1 << lg) < v) ++lg;                                   // ceil(log2 members)
+    bool exact = true;
+    for (int a = 0; a < 3; ++a) {
+      const long long vi = (long long)((key >> (21 * a)) & ((1ULL << 21) - 1));
+      const double origin = hdr[b].minb[a] - voxel * 0.5;
+      const double lo = origin + (double)vi * voxel, hi = lo + voxel;
+      const int emax = f32_biased_exp(fmax(fabs(lo), fabs(hi))) + 1;          // members may exceed the interval by a rounding
+      int emin;
+      if (voxel_holds_zero(origin, vi, voxel)) emin = measured ? 255 - (int)measured : emax;     // nothing small and non-zero seen
+      else emin = f32_biased_exp(fmin(fabs(lo), fabs(hi))) - 1;
+      // all members are multiples of 2^(emin - 23), every partial sum is below 2^(emax + 1 + lg): exact in 53 bits?
+      exact = exact && (emax + 1 + lg) - (emin - 23) <= 53;
+    }
+    sflag[s] = exact ? 1u : 0u;
+  }
   lc[(size_t)b * n + i] = v;
 }
 
@@ -209,21 +327,132 @@ __global__ __launch_bounds__(1024) void voxel_rank_kernel(const int32_t *__restr
   if (t == 0) out_counts[b] = nv;
 }
 
+// The same ranking beyond 65 536 points, on (chunks x clouds) workgroups: chunk totals -> one small scan per cloud -> ranks and
+// offsets behind the chunk's base (a chunk = VOX_CHUNK points = 16 waves x 1024).
+__global__ __launch_bounds__(1024) void voxel_rank_part_kernel(const int32_t *__restrict__ lc, int n, int nchunk,
+                                                               int32_t *__restrict__ part) {
+  __shared__ int s_f[16], s_c[16];
+  const int b = blockIdx.y, ck = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  lc += (size_t)b * n;
+  int facc = 0, cacc = 0;
+  const int hi = min(n, (ck + 1) * VOX_CHUNK);
+  for (int i = ck * VOX_CHUNK + t; i < hi; i += 1024) {
+    const int c = lc[i];
+    facc += c > 0 ? 1 : 0;
+    cacc += c;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { facc += __shfl_xor(facc, o); cacc += __shfl_xor(cacc, o); }
+  if (lane == 0) { s_f[wave] = facc; s_c[wave] = cacc; }
+  __syncthreads();
+  if (t == 0) {
+    int f = 0, c = 0;
+    for (int w = 0; w < 16; ++w) { f += s_f[w]; c += s_c[w]; }
+    part[(size_t)b * (nchunk * 2 + 2) + ck * 2] = f;
+    part[(size_t)b * (nchunk * 2 + 2) + ck * 2 + 1] = c;
+  }
+}
+// one wave per cloud: exclusive scan of the chunk totals in place; totals -> out_counts, part[2 nchunk ..]
+__global__ __launch_bounds__(64) void voxel_rank_scan_kernel(int nchunk, int32_t *__restrict__ part, int32_t *__restrict__ out_counts) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int32_t *p = part + (size_t)b * (nchunk * 2 + 2);
+  int bf = 0, bc = 0;
+  for (int c0 = 0; c0 < nchunk; c0 += 64) {
+    const int c = c0 + lane;
+    const int f = c < nchunk ? p[c * 2] : 0, k = c < nchunk ? p[c * 2 + 1] : 0;
+    int fi = f, ki = k;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(fi, o), v = __shfl_up(ki, o);
+      if (lane >= o) { fi += u; ki += v; }
+    }
+    if (c < nchunk) { p[c * 2] = bf + fi - f; p[c * 2 + 1] = bc + ki - k; }
+    bf += __shfl(fi, 63);
+    bc += __shfl(ki, 63);
+  }
+  if (lane == 0) { out_counts[b] = bf; p[nchunk * 2] = bc; }
+}
+__global__ __launch_bounds__(1024) void voxel_rank_apply_kernel(const int32_t *__restrict__ pslot, const int32_t *__restrict__ lc,
+                                                                int n, int nchunk, unsigned nslots, const int32_t *__restrict__ part,
+                                                                const int32_t *__restrict__ out_counts, int32_t *__restrict__ srank,
+                                                                int32_t *__restrict__ off) {
+  __shared__ int s_f[16], s_c[16];
+  const int b = blockIdx.y, ck = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  pslot += (size_t)b * n;
+  lc += (size_t)b * n;
+  srank += (size_t)b * nslots;
+  off += (size_t)b * (n + 1);
+  const int lo = ck * VOX_CHUNK + wave * 1024, hi = min(n, lo + 1024);        // this wave's run of the chunk
+  int facc = 0, cacc = 0;
+  for (int i = lo + lane; i < hi; i += 64) {
+    const int c = lc[i];
+    facc += c > 0 ? 1 : 0;
+    cacc += c;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { facc += __shfl_xor(facc, o); cacc += __shfl_xor(cacc, o); }
+  if (lane == 0) { s_f[wave] = facc; s_c[wave] = cacc; }
+  __syncthreads();
+  int rf = part[(size_t)b * (nchunk * 2 + 2) + ck * 2], rc = part[(size_t)b * (nchunk * 2 + 2) + ck * 2 + 1];
+  for (int w = 0; w < wave; ++w) { rf += s_f[w]; rc += s_c[w]; }
+  for (int i0 = lo; i0 < hi; i0 += 64) {
+    const int i = i0 + lane;
+    const int c = i < hi ? lc[i] : 0;
+    const int sl = i < hi ? pslot[i] : -1;
+    const bool leader = c > 0;
+    const unsigned long long m = __ballot(leader);
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (leader) {
+      const int pos = rf + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+      srank[sl] = pos;
+      off[pos] = rc + incl - c;
+    }
+    rf += __popcll(m);
+    rc += __shfl(incl, 63);
+  }
+  // off[a] = total members for a in [voxels, n]: every chunk fills the part of that tail that lies in its own index range
+  const int nv = out_counts[b], total = part[(size_t)b * (nchunk * 2 + 2) + nchunk * 2];
+  for (int a = ck * VOX_CHUNK + t; a < min(n + 1, (ck + 1) * VOX_CHUNK); a += 1024)
+    if (a >= nv) off[a] = total;
+  if (ck == nchunk - 1 && t == 0) off[n] = total;
+}
+
 // member lists: every point takes a ticket in its voxel's segment (arbitrary order; seg_order() sorts the segments)
 __global__ __launch_bounds__(256) void voxel_fill_kernel(const int32_t *__restrict__ pslot, const int32_t *__restrict__ srank,
-                                                         const int32_t *__restrict__ off, int *__restrict__ cursor, int n,
+                                                         const int32_t *__restrict__ off, int *__restrict__ cursor,
+                                                         const unsigned *__restrict__ first, const unsigned *__restrict__ sflag, int n,
                                                          unsigned nslots, int32_t *__restrict__ vidx,
-                                                         int32_t *__restrict__ list) {
+                                                         int32_t *__restrict__ list, uint8_t *__restrict__ skip) {
   const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (i >= n) return;
-  const int slot = pslot[(size_t)b * n + i];
+  const int lane = threadIdx.x & 63;
+  const int slot = i < n ? pslot[(size_t)b * n + i] : -1;
+  // runs of consecutive points in one voxel take their tickets together: the run's first lane adds the run's length
+  const int prev_slot = __shfl_up(slot, 1);
+  const bool head = slot >= 0 && !(lane > 0 && prev_slot == slot);
+  const unsigned long long heads = __ballot(head), mine = __ballot(slot >= 0);
   int v = -1;
   if (slot >= 0) {
+    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    const int head_lane = 63 - __builtin_clzll(below);
+    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1)) << (lane + 1);
+    // the run also ends at the first lane without a voxel
+    const unsigned long long gaps = lane == 63 ? 0ull : ((~mine) >> (lane + 1)) << (lane + 1);
+    const unsigned long long stop = above | gaps;
+    const int end = stop ? __builtin_ctzll(stop) : 64;
+    int base = 0;
+    if (head) base = atomicAdd(&cursor[(size_t)b * nslots + slot], end - lane);
+    base = __shfl(base, head_lane);
     v = srank[(size_t)b * nslots + slot];
-    const int pos = off[(size_t)b * (n + 1) + v] + atomicAdd(&cursor[(size_t)b * nslots + slot], 1);
+    const int pos = off[(size_t)b * (n + 1) + v] + base + (lane - head_lane);
     list[(size_t)b * n + pos] = i;
+    if (first[(size_t)b * nslots + slot] == (unsigned)i) skip[(size_t)b * n + v] = (uint8_t)sflag[(size_t)b * nslots + slot];
   }
-  vidx[(size_t)b * n + i] = v;
+  if (i < n) vidx[(size_t)b * n + i] = v;
 }
 
 // one thread per output row: the voxel's members added in ascending index order, float64, then the mean; rows past
@@ -249,6 +478,49 @@ __global__ __launch_bounds__(256) void voxel_mean_kernel(const float *__restrict
   o[0] = sx; o[1] = sy; o[2] = sz;
 }
 
+// the same, one WAVE per output row, for frame-sized clouds (~100 members per voxel): a voxel flagged exact (skip != 0: its
+// float64 sums are the same in any order and any association) is summed lane-strided and folded by shuffles; any other voxel
+// keeps the sequential ascending loop (lane 0).  Rows past the cloud's voxel count are zero.
+__global__ __launch_bounds__(256) void voxel_mean_wave_kernel(const float *__restrict__ pts, const int32_t *__restrict__ off,
+                                                              const int32_t *__restrict__ list, const int32_t *__restrict__ counts,
+                                                              const uint8_t *__restrict__ skip, int n, double *__restrict__ out) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int nv = counts[b];
+  const float *p = pts + (size_t)b * n * 3;
+  const int32_t *l = list + (size_t)b * n;
+  const int a0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;          // 16 rows per wave, one after the other
+  if (a0 >= nv) {                                                      // nothing but zero rows here: one coalesced store
+    const int rows = min(16, n - a0);
+    if (lane < rows * 3) out[((size_t)b * n + a0) * 3 + lane] = 0.0;
+    return;
+  }
+  for (int a = a0; a < min(a0 + 16, n); ++a) {
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    if (a < nv) {                                                      // wave-uniform
+      const int lo = off[(size_t)b * (n + 1) + a], hi = off[(size_t)b * (n + 1) + a + 1];
+      if (skip[(size_t)b * n + a]) {
+        for (int t = lo + lane; t < hi; t += 64) {
+          const int e = l[t];
+          sx += (double)p[e * 3]; sy += (double)p[e * 3 + 1]; sz += (double)p[e * 3 + 2];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
+      } else if (lane == 0) {
+        for (int t = lo; t < hi; ++t) {
+          const int e = l[t];
+          sx += (double)p[e * 3]; sy += (double)p[e * 3 + 1]; sz += (double)p[e * 3 + 2];
+        }
+      }
+      const double c = (double)(hi - lo);
+      sx /= c; sy /= c; sz /= c;
+    }
+    if (lane == 0) {
+      double *o = out + ((size_t)b * n + a) * 3;
+      o[0] = sx; o[1] = sy; o[2] = sz;
+    }
+  }
+}
+
 static unsigned voxel_slots(int n) {
   unsigned s = 1024;
   while (s < 2u * (unsigned)n) s <<= 1;
@@ -259,8 +531,10 @@ struct VoxelWs {
   unsigned long long *keys;
   unsigned *first;
   int *cnt, *cursor;
+  unsigned *sflag;
   VoxelHeader *hdr;
-  int32_t *srank, *pslot, *vidx, *off, *list;
+  int32_t *srank, *pslot, *vidx, *off, *list, *part;
+  uint8_t *skip;
   size_t ff_bytes, zero_bytes, bytes;
 };
 
@@ -276,6 +550,7 @@ static VoxelWs voxel_carve(void *base, int b, int n) {
   const size_t z0 = o;
   w.cnt = (int *)take(B * S * 4);
   w.cursor = (int *)take(B * S * 4);
+  w.sflag = (unsigned *)take(B * S * 4);
   w.hdr = (VoxelHeader *)take(B * sizeof(VoxelHeader));
   w.zero_bytes = o - z0;
   w.srank = (int32_t *)take(B * S * 4);
@@ -283,6 +558,8 @@ static VoxelWs voxel_carve(void *base, int b, int n) {
   w.vidx = (int32_t *)take(B * N * 4);
   w.off = (int32_t *)take(B * (N + 1) * 4);
   w.list = (int32_t *)take(B * N * 4);
+  w.skip = (uint8_t *)take(B * N);
+  w.part = (int32_t *)take(B * ((N + VOX_CHUNK - 1) / VOX_CHUNK * 3 + 2) * 4);      // chunk minima (3 floats) / chunk totals (2 ints + 2)
   w.bytes = o;
   return w;
 }
@@ -635,16 +912,36 @@ extern "C" int gn_voxel_down_sample_batched(const float *points, const int32_t *
     return GN_ERR_LAUNCH;
   }
   const dim3 gp((n + 255) / 256, b);
-  hipLaunchKernelGGL(voxel_minbound_kernel, dim3(b), dim3(1024), 0, s, points, n_valid, n, w.hdr, status);
+  const int nchunk = (n + VOX_CHUNK - 1) / VOX_CHUNK;
+  const bool wide = n > 65536;          // a whole frame's cloud: the per-cloud passes on (chunks x clouds) workgroups
+  if (wide) {
+    hipLaunchKernelGGL(voxel_minbound_part_kernel, dim3(nchunk, b), dim3(1024), 0, s, points, n_valid, n, nchunk, (float *)w.part);
+    hipLaunchKernelGGL(voxel_minbound_fold_kernel, dim3(b), dim3(64), 0, s, (const float *)w.part, nchunk, w.hdr, status);
+  } else {
+    hipLaunchKernelGGL(voxel_minbound_kernel, dim3(b), dim3(1024), 0, s, points, n_valid, n, w.hdr, status);
+  }
   hipLaunchKernelGGL(voxel_insert_kernel, gp, dim3(256), 0, s, points, n_valid, n, voxel_size, w.hdr, w.keys, w.first, w.cnt,
-                     w.pslot, slots - 1, status);
+                     w.sflag, w.pslot, slots - 1, status);
   // (lc lives in w.vidx until the fill pass overwrites it with the points' voxel ranks)
-  hipLaunchKernelGGL(voxel_leader_kernel, gp, dim3(256), 0, s, w.pslot, w.first, w.cnt, n, slots, w.vidx);
-  hipLaunchKernelGGL(voxel_rank_kernel, dim3(b), dim3(1024), 0, s, w.pslot, w.vidx, n, slots, w.srank, w.off, out_counts);
-  hipLaunchKernelGGL(voxel_fill_kernel, gp, dim3(256), 0, s, w.pslot, w.srank, w.off, w.cursor, n, slots, w.vidx, w.list);
+  hipLaunchKernelGGL(voxel_leader_kernel, gp, dim3(256), 0, s, w.pslot, w.first, w.cnt, w.keys, w.sflag, w.hdr, voxel_size, n,
+                     slots, w.vidx);
+  if (wide) {
+    hipLaunchKernelGGL(voxel_rank_part_kernel, dim3(nchunk, b), dim3(1024), 0, s, w.vidx, n, nchunk, w.part);
+    hipLaunchKernelGGL(voxel_rank_scan_kernel, dim3(b), dim3(64), 0, s, nchunk, w.part, out_counts);
+    hipLaunchKernelGGL(voxel_rank_apply_kernel, dim3(nchunk, b), dim3(1024), 0, s, w.pslot, w.vidx, n, nchunk, slots, w.part,
+                       out_counts, w.srank, w.off);
+  } else {
+    hipLaunchKernelGGL(voxel_rank_kernel, dim3(b), dim3(1024), 0, s, w.pslot, w.vidx, n, slots, w.srank, w.off, out_counts);
+  }
+  hipLaunchKernelGGL(voxel_fill_kernel, gp, dim3(256), 0, s, w.pslot, w.srank, w.off, w.cursor, w.first, w.sflag, n, slots, w.vidx,
+                     w.list, w.skip);
   GN_CHECK_LAUNCH("voxel_down_sample");
-  if (int rc = seg_order(w.vidx, b, n, n, w.off, w.list, s)) return rc;
-  hipLaunchKernelGGL(voxel_mean_kernel, gp, dim3(256), 0, s, points, w.off, w.list, out_counts, n, out);
+  const char *oe = getenv("GN_VOXEL_ORDER");          // GN_VOXEL_ORDER=all: order every member list (round 4's form; A/B, tests)
+  if (int rc = seg_order(w.vidx, b, n, n, w.off, w.list, s, (oe && oe[0] == 'a') ? nullptr : w.skip)) return rc;
+  if (wide && !(oe && oe[0] == 'a'))
+    hipLaunchKernelGGL(voxel_mean_wave_kernel, dim3((n + 63) / 64, b), dim3(256), 0, s, points, w.off, w.list, out_counts, w.skip, n, out);
+  else
+    hipLaunchKernelGGL(voxel_mean_kernel, gp, dim3(256), 0, s, points, w.off, w.list, out_counts, n, out);
   GN_CHECK_LAUNCH("voxel_down_sample");
   return GN_OK;
 }

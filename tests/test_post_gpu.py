@@ -179,6 +179,49 @@ def test_voxel_down_sample_batched_bit_exact_and_deterministic(voxel):
     assert np.array_equal(one, o[1, :c[1]])
 
 
+def test_voxel_down_sample_orders_only_where_the_order_matters(monkeypatch):
+    """Round 5: a voxel's member list is put in ascending order only when its float64 sums could depend on the order (some
+    partial sum inexact) -- decided per voxel from exponent bounds (csrc/post.hip).  (a) a cloud built so that the order DOES
+    matter in some voxels (coordinates of 1e-30 .. 1e-12 beside 5e-3 in the voxel that holds zero: sums of such terms round
+    differently in different orders): still bit-identical to the sequential restatement, i.e. those voxels are ordered; (b) a
+    camera-frame-sized cloud (300 000 points: the (chunks x clouds) min-bound / ranking passes) with ~100 members per voxel: bit-
+    identical too, and identical to the run that orders EVERY list (GN_VOXEL_ORDER=all, round 4's form); (c) n just across the
+    65 536 switch"""
+    from graspnet_amd import postprocess as P, synthetic as S
+    from oracle import post_oracle as PO
+    rng = np.random.default_rng(17)
+    n = 6000
+    tiny = rng.uniform(-0.004, 0.004, size=(n, 3)).astype(np.float32)          # everything around the origin: voxels that hold zero
+    tiny[::3, 0] = (10.0 ** rng.uniform(-30, -12, size=len(tiny[::3]))).astype(np.float32) * rng.choice([-1, 1], size=len(tiny[::3]))
+    tiny[1::5, 1] = (2.0 ** rng.integers(-60, -30, size=len(tiny[1::5]))).astype(np.float32)
+    tiny[0] = [-0.02, -0.02, -0.02]                                           # the min bound away from the cluster
+    # the sequential float64 sum of these terms really is order-dependent (else this case tests nothing)
+    col = tiny[(np.abs(tiny[:, 0]) < 0.004), 0].astype(np.float64)
+    assert np.sum(col) != np.sum(col[::-1]) or np.sum(np.sort(col)) != np.sum(col)
+    big = S.make_cloud(1234, 300000, "surface")
+    edge = S.make_cloud(1235, 65537, "uniform")
+    for name, cloud, voxel in (("tiny", tiny, 0.01), ("frame", big, 0.01), ("edge", edge, 0.005)):
+        pts = torch.from_numpy(cloud).unsqueeze(0).cuda()
+        out, cnt, status = P.voxel_down_sample_batched(pts, voxel)
+        want = PO.voxel_down_sample_ordered(cloud, voxel)
+        c = int(cnt[0])
+        assert not status.any() and c == len(want), (name, c, len(want))
+        assert np.array_equal(out[0, :c].cpu().numpy(), want), name
+        monkeypatch.setenv("GN_VOXEL_ORDER", "all")
+        out_all, cnt_all, _ = P.voxel_down_sample_batched(pts, voxel)
+        monkeypatch.delenv("GN_VOXEL_ORDER")
+        assert torch.equal(out_all, out) and torch.equal(cnt_all, cnt), name
+    # two clouds of different sizes in one call through the wide path (padding rows behind n_valid)
+    pair = np.zeros((2, 120000, 3), np.float32)
+    pair[0] = S.make_cloud(1236, 120000, "uniform")
+    pair[1, :70000] = S.make_cloud(1237, 70000, "surface")
+    nv = torch.tensor([120000, 70000], dtype=torch.int32, device="cuda")
+    out, cnt, status = P.voxel_down_sample_batched(torch.from_numpy(pair).cuda(), 0.01, n_valid=nv)
+    for b, m in ((0, 120000), (1, 70000)):
+        want = PO.voxel_down_sample_ordered(pair[b], 0.01, n_valid=m)
+        assert int(cnt[b]) == len(want) and np.array_equal(out[b, :len(want)].cpu().numpy(), want) and not out[b, len(want):].any()
+
+
 def test_voxel_down_sample_reports_a_grid_beyond_2_21_cells():
     from graspnet_amd import postprocess as P
     pts = torch.tensor([[[0.0, 0.0, 0.0], [3.0e4, 0.0, 0.0], [0.001, 0.0, 0.0]]], device="cuda")

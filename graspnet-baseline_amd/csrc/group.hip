@@ -105,6 +105,28 @@ __global__ __launch_bounds__(256) void group_points_vec_kernel(const float *__re
   }
 }
 
+// the same for C <= 4 channels (the xyz rows of SA1 / CloudCrop): ONE thread serves all channels of its 4 elements -- the
+// index quad is loaded once (the per-channel form fetched it once per channel: 1.7-2.0 x the algorithmic bytes by PMC,
+// profiles/r4_ops_summary.txt) and all 4 C gathers are in flight together before the first 16-byte store
+template <int C>
+__global__ __launch_bounds__(256) void group_points_vec_small_kernel(const float *__restrict__ points,
+                                                                     const int32_t *__restrict__ idx, int n, int ne,
+                                                                     float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= (ne >> 2)) return;
+  using i32x4 = __attribute__((ext_vector_type(4))) int;
+  const i32x4 a = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(idx + (size_t)b * ne) + q);
+  f32x4 v[C];
+#pragma unroll
+  for (int l = 0; l < C; ++l) {
+    const float *r = points + ((size_t)b * C + l) * n;
+    v[l] = f32x4{r[a[0]], r[a[1]], r[a[2]], r[a[3]]};
+  }
+#pragma unroll
+  for (int l = 0; l < C; ++l) __builtin_nontemporal_store(v[l], reinterpret_cast<f32x4 *>(out + ((size_t)b * C + l) * ne) + q);
+}
+
 // group_points_gpu.cu:48-69
 __global__ __launch_bounds__(256) void group_points_grad_kernel(const float *__restrict__ grad_out,
                                                                 const int32_t *__restrict__ idx, int c,
@@ -286,6 +308,11 @@ extern "C" int gn_group_points(const float *points, const int32_t *idx, int b, i
     else if (cg == 4) rc = launch(group_points_lds_kernel<4>);
     else rc = launch(group_points_lds_kernel<2>);
     if (rc) return rc;
+  } else if (vec && c <= 4) {
+    dim3 grid((unsigned)(((ne >> 2) + 255) / 256), 1, b);
+#define GN_GP_SMALL(CC) hipLaunchKernelGGL(group_points_vec_small_kernel<CC>, grid, dim3(256), 0, as_stream(stream), points, idx, n, (int)ne, out)
+    if (c == 1) GN_GP_SMALL(1); else if (c == 2) GN_GP_SMALL(2); else if (c == 3) GN_GP_SMALL(3); else GN_GP_SMALL(4);
+#undef GN_GP_SMALL
   } else if (vec) {
     dim3 grid((unsigned)(((ne >> 2) + 255) / 256), chan_split(c), b);
     hipLaunchKernelGGL(group_points_vec_kernel, grid, dim3(256), 0, as_stream(stream), points, idx, c, n, (int)ne, out);

@@ -90,7 +90,7 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 constexpr unsigned long long KNN_NONE = ~0ULL;
 
 // K: list length (>= k), QW: queries per wave
-template <int K, int QW>
+template <int K, int QW, bool D3>
 __global__ __launch_bounds__(256) void knn_wave_kernel(const float *__restrict__ ref, const float *__restrict__ query, int d,
                                                        int nr, int nq, int k, int64_t *__restrict__ idx) {
   const int b = blockIdx.y;
@@ -108,32 +108,89 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float *__restrict__
   for (int qi = 0; qi < QW; ++qi)
 #pragma unroll
     for (int t = 0; t < K; ++t) best[qi][t] = KNN_NONE;
-  for (int r = lane; r < nr; r += 64) {
-    float dd[QW];
+  // U reference points per lane and pass: their D * U loads are all requested before the first distance is formed (one L2
+  // round trip per pass instead of one per point: at 20 000 x 1 024, one query per wave, the loop was 313 dependent round
+  // trips -- 0.118 ms for ~15 us of arithmetic); D = 3 (the reference's call sites, utils/label_generation.py:58-60,84-86) is
+  // unrolled in full, any other dimension walks h with the U points side by side
+  constexpr int U = QW == 1 ? 8 : 4;
+  auto insert_pass = [&](int r0, const float (&dd)[U][QW]) {
 #pragma unroll
-    for (int qi = 0; qi < QW; ++qi) dd[qi] = 0.f;
-    for (int h = 0; h < d; ++h) {
-      const float rv = ref[(size_t)h * nr + r];
+    for (int u = 0; u < U; ++u) {           // ascending r within the lane: a later equal distance never displaces an earlier one
+      const int r = r0 + u * 64;
+      if (r >= nr) break;
 #pragma unroll
       for (int qi = 0; qi < QW; ++qi) {
-        const int q = min(q0 + qi, nq - 1);
-        const float t = rv - query[(size_t)h * nq + q];      // wave-uniform address
-        dd[qi] = fp_acc_sq(dd[qi], t);                          // knn.cu:89-90
+        // a NaN distance sorts after every number (the reference's strict `>` never moves anything past it either)
+        const unsigned bits = dd[u][qi] == dd[u][qi] ? __float_as_uint(dd[u][qi]) : 0x7fc00000u;
+        unsigned long long key = ((unsigned long long)bits << 32) | (unsigned)r;
+        // insertion keeping the K smallest: bubble the new key down the sorted list
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+          const unsigned long long cur = best[qi][t];
+          const bool less = key < cur;
+          best[qi][t] = less ? key : cur;
+          key = less ? cur : key;
+        }
       }
     }
+  };
+  if (D3) {
+    // the query's coordinates once (wave-uniform), the reference points of pass p+1 requested before pass p is evaluated
+    float qv[QW][3];
 #pragma unroll
-    for (int qi = 0; qi < QW; ++qi) {
-      // a NaN distance sorts after every number (the reference's strict `>` never moves anything past it either)
-      const unsigned bits = dd[qi] == dd[qi] ? __float_as_uint(dd[qi]) : 0x7fc00000u;
-      unsigned long long key = ((unsigned long long)bits << 32) | (unsigned)r;
-      // insertion keeping the K smallest: bubble the new key down the sorted list
+    for (int qi = 0; qi < QW; ++qi)
 #pragma unroll
-      for (int t = 0; t < K; ++t) {
-        const unsigned long long cur = best[qi][t];
-        const bool less = key < cur;
-        best[qi][t] = less ? key : cur;
-        key = less ? cur : key;
+      for (int h = 0; h < 3; ++h) qv[qi][h] = query[(size_t)h * nq + min(q0 + qi, nq - 1)];
+    float cur[U][3], nxt[U][3];
+    auto fetch = [&](int r0, float (&rv)[U][3]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = min(r0 + u * 64, nr - 1);
+#pragma unroll
+        for (int h = 0; h < 3; ++h) rv[u][h] = ref[(size_t)h * nr + r];
       }
+    };
+    if (lane < nr) fetch(lane, cur);
+    for (int r0 = lane; r0 < nr; r0 += 64 * U) {
+      const bool more = r0 + 64 * U < nr;
+      if (more) fetch(r0 + 64 * U, nxt);
+      float dd[U][QW];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi) {
+          float acc = 0.f;
+#pragma unroll
+          for (int h = 0; h < 3; ++h) acc = fp_acc_sq(acc, cur[u][h] - qv[qi][h]);       // knn.cu:89-90, h ascending
+          dd[u][qi] = acc;
+        }
+      insert_pass(r0, dd);
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int h = 0; h < 3; ++h) cur[u][h] = nxt[u][h];
+      }
+    }
+  } else {
+    for (int r0 = lane; r0 < nr; r0 += 64 * U) {
+      float dd[U][QW];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi) dd[u][qi] = 0.f;
+      for (int h = 0; h < d; ++h) {
+        float rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) rv[u] = ref[(size_t)h * nr + min(r0 + u * 64, nr - 1)];
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi) {
+          const float qvv = query[(size_t)h * nq + min(q0 + qi, nq - 1)];
+#pragma unroll
+          for (int u = 0; u < U; ++u) dd[u][qi] = fp_acc_sq(dd[u][qi], rv[u] - qvv);
+        }
+      }
+      insert_pass(r0, dd);
     }
   }
   // merge the 64 lists: k rounds of a wave-wide minimum; its owner pops
@@ -171,8 +228,14 @@ extern "C" int GN_FP_ENTRY(gn_knn)(const float *ref, const float *query, int b, 
     // four queries); one query per wave otherwise -- 1024 queries = 256 workgroups
     const bool qw4 = (long)b * nq >= 4L * 4 * 1024;
 #define GN_KNN_LAUNCH(K, QW)                                                                                          \
-  hipLaunchKernelGGL((knn_wave_kernel<K, QW>), dim3(((nq + QW - 1) / QW + 3) / 4, b), dim3(256), 0, as_stream(stream), ref, \
-                     query, d, nr, nq, k, idx)
+  do {                                                                                                                \
+    if (d == 3)                                                                                                       \
+      hipLaunchKernelGGL((knn_wave_kernel<K, QW, true>), dim3(((nq + QW - 1) / QW + 3) / 4, b), dim3(256), 0, as_stream(stream), \
+                         ref, query, d, nr, nq, k, idx);                                                              \
+    else                                                                                                              \
+      hipLaunchKernelGGL((knn_wave_kernel<K, QW, false>), dim3(((nq + QW - 1) / QW + 3) / 4, b), dim3(256), 0, as_stream(stream), \
+                         ref, query, d, nr, nq, k, idx);                                                              \
+  } while (0)
 #define GN_KNN_K(K) do { if (qw4) GN_KNN_LAUNCH(K, 4); else GN_KNN_LAUNCH(K, 1); } while (0)
     if (k == 1) GN_KNN_K(1);
     else if (k == 2) GN_KNN_K(2);

@@ -114,7 +114,7 @@ def cpu_baseline(n_points, reps1, reps8):
 
 def pmc_file():
     """The committed PMC passes of the bench command (HBM bytes per launch); newest round first."""
-    for name in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1g_pmc_traffic.json"):
+    for name in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1g_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:

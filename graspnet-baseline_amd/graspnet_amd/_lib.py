@@ -53,6 +53,7 @@ SIGNATURES = {
     "gn_get_fp_policy": (_c_int, []),
     "gn_stream_capture_id": (_c_int, [_c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
     "gn_fps_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
+    "gn_fps_tie_is_free": (_c_int, [_c_int]),
     "gn_fps_prefix_check": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p,
                                      _c_void_p]),
     "gn_furthest_point_sampling": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,

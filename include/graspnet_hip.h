@@ -98,6 +98,9 @@ int gn_get_fp_policy(void);
  *                       prefix (provably what the full computation returns,
  *                       models/backbone.py:110-119) and is written directly. */
 size_t gn_fps_workspace_bytes(int b, int n);
+/* 1 when a tie_out request does not change the kernel that serves n points, 0 when it moves the call onto the (slightly
+ * slower) tie-tracking kernel: lets a caller that only MIGHT chain calls decide whether the report is worth asking for. */
+int gn_fps_tie_is_free(int n);
 /* For callers that chain sampling calls WITHOUT the fused path (the reference model does: backbone.py:105-121 samples the
  * 2048 sampled points again for 1024, ...): tie2[b] = tie1[b] if pts2 (B,n2,3) is bit for bit pts1[inds1[0..n2)] -- the
  * points an earlier call on pts1 (B,n1,3) picked, in its order, inds1 (B,m1>=n2), tie1 its tie_out -- else 0.  tie2 is then a

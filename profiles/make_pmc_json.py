@@ -67,13 +67,13 @@ if os.path.exists(s1):
                          mfma_busy_share_of_simd_cycles=(m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) /
                                                          max(m.get("GRBM_GUI_ACTIVE", 1) / 8.0 * 1024, 1)))
     res["crop_unique_mlp_pool"] = e
-for name, fn, spec in (("ops", "%s_ops_summary.txt", {"group_points_sa2": ["group_points_lds_kernel"], "group_points_sa1": ["group_points_vec_kernel"],
+for name, fn, spec in (("ops", "%s_ops_summary.txt", {"group_points_sa2": ["group_points_lds_kernel"], "group_points_sa1": ["group_points_vec_small_kernel", "group_points_vec_kernel"],
                                                        "ball_query_sa1_cold": ["grid_build_kernel", "ball_grid_kernel<false>"],
                                                        "cylinder_query_cold": ["grid_build_kernel", "ball_grid_kernel<true>"],
                                                        # round 4: a query on a cloud the previous query binned reuses its grid
                                                        "ball_query_sa1": ["ball_grid_kernel<false>"],
                                                        "cylinder_query": ["ball_grid_kernel<true>"]}),
-                       ("ops_n50000", "%s_ops_n50000_summary.txt", {"group_points_sa1_n50000": ["group_points_vec_kernel"],
+                       ("ops_n50000", "%s_ops_n50000_summary.txt", {"group_points_sa1_n50000": ["group_points_vec_small_kernel", "group_points_vec_kernel"],
                                                                     "ball_query_sa1_n50000": ["grid_build_kernel", "ball_grid_kernel<false>"],
                                                                     "furthest_point_sampling_n50000": ["fps_cell_kernel"]})):
     path = os.path.join(HERE, fn % tag)

@@ -9,7 +9,7 @@ from collections import defaultdict
 def short(name):
     name = name.replace("(anonymous namespace)::", "")
     name = name.split("(")[0]
-    for pre in ("void gn::", "gn::"):
+    for pre in ("void gn::fp0::", "gn::fp0::", "void gn::fp1::", "gn::fp1::", "void gn::fp2::", "gn::fp2::", "void gn::", "gn::"):
         if name.startswith(pre):
             name = name[len(pre):]
     return name[:70]

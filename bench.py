@@ -952,6 +952,13 @@ def main():
             "all_mlp_kernels": {"ms": mlp_ms, "algorithmic_tflops": (mlp_flop / (mlp_ms * 1e-3) / 1e12) if mlp_flop and mlp_ms else None},
             "op_rooflines": op_rooflines(dev) if (world == 1 and "ops" in legs) else None,
             "kernel_ms": {k: round(v, 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])},
+            # round-4 VERDICT item 1: the per-point chains (FP1, FP2, ApproachNet, heads, the three hoisted linears) in the
+            # single-stream pass (latency tile shapes: heads on 128-row fp32 tiles, ApproachNet on 64-row fp32 tiles)
+            "per_point_chains": {"sum_ms": sum(v for k, v in stages.items() if k.startswith(("fp_interp_mlp", "approach_mlp", "heads_mlp", "point_linear"))),
+                                 "kernels_ms": {k: round(v, 4) for k, v in stages.items()
+                                                if k.startswith(("fp_interp_mlp", "approach_mlp", "heads_mlp", "point_linear"))},
+                                 "tile_policy_of_the_timed_legs": "throughput (64- / 128-row fp32 tiles) on %d streams; latency shapes on one"
+                                                                  % len(streams)},
             "grasps_last_step": grasps_last,
         }
         out.update(extra)

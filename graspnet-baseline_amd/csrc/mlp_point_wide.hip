@@ -327,6 +327,14 @@ struct GroupStage {
   }
 };
 
+// a workgroup barrier that orders LDS traffic only: __syncthreads() also drains every outstanding global request
+// (s_waitcnt vmcnt(0)) -- here the next weight chunk and the next input group, requested on purpose ahead of the barrier
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 enum { WLOAD_PLAIN = 0, WLOAD_FP = 1 };
 
 // NL layers C0 -> C1 (relu) [-> C2 (relu)] -> last (to global, RELU_OUT); widths as in point_mlp_split_kernel.  CHREG:
@@ -372,7 +380,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void point_mlp_wide_kernel(PointSpl
     auto stage1 = [&](int g) {       // group g was requested a group ago: publish it, request the one after it
       gs.template publish<XSF>(buf, g, tid);
       if ((g + 1) * GC < C0) gs.request(a.x, row0, a.nrows, g + 1, tid);
-      __syncthreads();
+      lds_barrier();
     };
     auto to_lds = [&](int ncols) {
       return [&, ncols](int mt, int nt, const f32x16 &acc) {

@@ -372,6 +372,29 @@ def test_model_parity_under_the_contracted_evaluation_policies(net, model_oracle
         oracle.set_fp_policy(prev_o)
 
 
+def test_tile_policies_give_identical_outputs(net, clouds):
+    """GraspNet.throughput (gn_set_point_tile_policy): the per-point chains on 64- / 128-row fp32 tiles (csrc/mlp_point_wide.hip:
+    fewer weight bytes per row, half as many workgroups; what PipelinedGraspNet and bench.py's multi-stream legs use) against
+    the latency shapes -- every key of end_points and the decoded rows bit for bit"""
+    from graspnet_amd import PipelinedGraspNet
+    x = clouds.cuda()
+    outs = []
+    for thr in (False, True):
+        net.throughput = thr
+        ep = net({"point_clouds": x})
+        g, c = net.decode_padded(ep)
+        torch.cuda.synchronize()
+        outs.append(({k: v.clone() for k, v in ep.items() if torch.is_tensor(v)}, g.clone(), c.clone()))
+    net.throughput = False
+    for k in outs[0][0]:
+        assert torch.equal(outs[0][0][k], outs[1][0][k]), k
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    pipe = PipelinedGraspNet(net, depth=3)
+    t = pipe.submit(x)
+    t.result()
+    assert net.throughput is False and torch.equal(t.grasps, outs[0][1]) and torch.equal(t.counts, outs[0][2])
+
+
 def _variants_module(golden_dir):
     import importlib.util
     spec = importlib.util.spec_from_file_location("make_golden_variants", os.path.join(golden_dir, "make_golden_variants.py"))

@@ -528,6 +528,8 @@ def main():
     # ---- isolated pass (outside every timed region): the same steps on ONE stream with HIP-event brackets around every
     # kernel launch on that stream, so a bracket is the kernel's own duration -- these feed the per-kernel roofline;
     # rocprofv3 --kernel-trace of `--streams 1 --legs headline` agrees with them (profiles/)
+    run_steps(net, sets, streams[:1], 2, gather=False)      # the latency tile shapes' kernels may meet their first call here
+    torch.cuda.synchronize()
     net.timing = {}
     run_steps(net, sets, streams[:1], min(args.steps, 12), gather=False)
     torch.cuda.synchronize()

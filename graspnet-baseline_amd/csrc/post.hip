@@ -478,9 +478,11 @@ __global__ __launch_bounds__(256) void voxel_mean_kernel(const float *__restrict
   o[0] = sx; o[1] = sy; o[2] = sz;
 }
 
-// the same, one WAVE per output row, for frame-sized clouds (~100 members per voxel): a voxel flagged exact (skip != 0: its
-// float64 sums are the same in any order and any association) is summed lane-strided and folded by shuffles; any other voxel
-// keeps the sequential ascending loop (lane 0).  Rows past the cloud's voxel count are zero.
+// the same for frame-sized clouds, one WAVE per 64 output rows: a row with few members (<= 8: a sparse scene, ~2 points per
+// voxel) is summed by its own lane, sequentially in list order (ascending where the order matters: seg_order() has put those
+// lists in order); a row with many members (a camera frame's table top: ~100 per voxel) is taken by the whole wave -- flagged
+// exact (skip != 0: its float64 sums are the same in any order and any association) lane-strided and folded by shuffles,
+// otherwise by its owner lane alone.  Rows past the cloud's voxel count are zero.
 __global__ __launch_bounds__(256) void voxel_mean_wave_kernel(const float *__restrict__ pts, const int32_t *__restrict__ off,
                                                               const int32_t *__restrict__ list, const int32_t *__restrict__ counts,
                                                               const uint8_t *__restrict__ skip, int n, double *__restrict__ out) {
@@ -488,36 +490,38 @@ __global__ __launch_bounds__(256) void voxel_mean_wave_kernel(const float *__res
   const int nv = counts[b];
   const float *p = pts + (size_t)b * n * 3;
   const int32_t *l = list + (size_t)b * n;
-  const int a0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;          // 16 rows per wave, one after the other
-  if (a0 >= nv) {                                                      // nothing but zero rows here: one coalesced store
-    const int rows = min(16, n - a0);
-    if (lane < rows * 3) out[((size_t)b * n + a0) * 3 + lane] = 0.0;
-    return;
+  const int a0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  if (a0 >= n) return;
+  const int a = a0 + lane;
+  double sx = 0.0, sy = 0.0, sz = 0.0;
+  int lo = 0, hi = 0;
+  if (a < nv) { lo = off[(size_t)b * (n + 1) + a]; hi = off[(size_t)b * (n + 1) + a + 1]; }
+  const int cnt = hi - lo;
+  const bool big = cnt > 8 && skip[(size_t)b * n + a] != 0;      // order-free and long: worth the whole wave
+  if (!big) {
+    for (int t = lo; t < hi; ++t) {
+      const int e = l[t];
+      sx += (double)p[e * 3]; sy += (double)p[e * 3 + 1]; sz += (double)p[e * 3 + 2];
+    }
   }
-  for (int a = a0; a < min(a0 + 16, n); ++a) {
-    double sx = 0.0, sy = 0.0, sz = 0.0;
-    if (a < nv) {                                                      // wave-uniform
-      const int lo = off[(size_t)b * (n + 1) + a], hi = off[(size_t)b * (n + 1) + a + 1];
-      if (skip[(size_t)b * n + a]) {
-        for (int t = lo + lane; t < hi; t += 64) {
-          const int e = l[t];
-          sx += (double)p[e * 3]; sy += (double)p[e * 3 + 1]; sz += (double)p[e * 3 + 2];
-        }
+  unsigned long long todo = __ballot(big);
+  while (todo) {
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int slo = __shfl(lo, src), shi = __shfl(hi, src);
+    double tx = 0.0, ty = 0.0, tz = 0.0;
+    for (int t = slo + lane; t < shi; t += 64) {
+      const int e = l[t];
+      tx += (double)p[e * 3]; ty += (double)p[e * 3 + 1]; tz += (double)p[e * 3 + 2];
+    }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
-      } else if (lane == 0) {
-        for (int t = lo; t < hi; ++t) {
-          const int e = l[t];
-          sx += (double)p[e * 3]; sy += (double)p[e * 3 + 1]; sz += (double)p[e * 3 + 2];
-        }
-      }
-      const double c = (double)(hi - lo);
-      sx /= c; sy /= c; sz /= c;
-    }
-    if (lane == 0) {
-      double *o = out + ((size_t)b * n + a) * 3;
-      o[0] = sx; o[1] = sy; o[2] = sz;
-    }
+    for (int o = 32; o > 0; o >>= 1) { tx += __shfl_xor(tx, o); ty += __shfl_xor(ty, o); tz += __shfl_xor(tz, o); }
+    if (lane == src) { sx = tx; sy = ty; sz = tz; }
+  }
+  if (a < n) {
+    if (cnt > 0) { const double c = (double)cnt; sx /= c; sy /= c; sz /= c; }
+    double *o = out + ((size_t)b * n + a) * 3;
+    o[0] = sx; o[1] = sy; o[2] = sz;
   }
 }
 
@@ -939,7 +943,7 @@ extern "C" int gn_voxel_down_sample_batched(const float *points, const int32_t *
   const char *oe = getenv("GN_VOXEL_ORDER");          // GN_VOXEL_ORDER=all: order every member list (round 4's form; A/B, tests)
   if (int rc = seg_order(w.vidx, b, n, n, w.off, w.list, s, (oe && oe[0] == 'a') ? nullptr : w.skip)) return rc;
   if (wide && !(oe && oe[0] == 'a'))
-    hipLaunchKernelGGL(voxel_mean_wave_kernel, dim3((n + 63) / 64, b), dim3(256), 0, s, points, w.off, w.list, out_counts, w.skip, n, out);
+    hipLaunchKernelGGL(voxel_mean_wave_kernel, dim3((n + 255) / 256, b), dim3(256), 0, s, points, w.off, w.list, out_counts, w.skip, n, out);
   else
     hipLaunchKernelGGL(voxel_mean_kernel, gp, dim3(256), 0, s, points, w.off, w.list, out_counts, n, out);
   GN_CHECK_LAUNCH("voxel_down_sample");
